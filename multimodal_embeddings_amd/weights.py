@@ -1,0 +1,196 @@
+"""Deterministic synthetic ViT-B/16 weights (SURVEY.md §8d "Synthetic inputs").
+
+The reference loads pretrained weights by NAME over the network
+(deprecated_package/embedder.py:75-79), which is unavailable offline, so the
+encoder of this build runs on seeded synthetic weights.  The generator is a
+counter-based integer hash, so the very same tensors are produced in the build
+container, on the GPU box and inside the golden-vector script without shipping
+343 MB of floats:
+
+    value(seed, tensor_id, i) = bf16_round( offset + std * z ),
+    z = (sum of twelve 16-bit lanes of splitmix64 words - 393210) / 65536
+
+(an Irwin-Hall approximation of N(0,1); every step is integer or a single
+correctly-rounded IEEE operation, so no libm call can differ between hosts).
+All values are bf16-representable: the reference itself runs its encoder with
+``torch_dtype=torch.bfloat16`` (embedder.py:78), and this lets the fp32 oracle
+and the bf16 MFMA path consume bit-identical parameters.
+
+Tensor names follow the Hugging Face ViT checkpoint layout
+(transformers/models/vit/modeling_vit.py; `ViTModel(add_pooling_layer=False)`)
+so the same dict loads into that class with ``load_state_dict`` when the golden
+vectors are generated.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+_MASK64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+@dataclass(frozen=True)
+class ViTGeometry:
+    """ViT-B/16 @224 (transformers ViTConfig defaults)."""
+
+    image_size: int = 224
+    patch_size: int = 16
+    num_channels: int = 3
+    hidden_size: int = 768
+    num_layers: int = 12
+    num_heads: int = 12
+    intermediate_size: int = 3072
+    layer_norm_eps: float = 1e-12
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch_size
+
+    @property
+    def num_patches(self) -> int:
+        return self.grid * self.grid
+
+    @property
+    def seq_len(self) -> int:
+        return self.num_patches + 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+    @property
+    def patch_dim(self) -> int:
+        return self.num_channels * self.patch_size * self.patch_size
+
+
+VIT_B16 = ViTGeometry()
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _MASK64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def counter_u64(seed: int, stream: int, n: int, word: int = 0) -> np.ndarray:
+    """n hashed 64-bit words for counters (seed, stream, i, word)."""
+    i = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = (
+            np.uint64(seed & 0xFFFF) * np.uint64(1 << 48)
+            + np.uint64(stream & 0xFFFF) * np.uint64(1 << 32)
+        )
+        key = _splitmix64(np.uint64(base) + np.uint64(word) * np.uint64(0xD1B54A32D192ED03))
+        return _splitmix64(key ^ (i * np.uint64(0x2545F4914F6CDD1D)))
+
+
+def irwin_hall_normal(seed: int, stream: int, n: int) -> np.ndarray:
+    """Approximate N(0,1) float32 samples with exact integer provenance."""
+    total = np.zeros(n, dtype=np.int64)
+    for word in range(3):
+        w = counter_u64(seed, stream, n, word)
+        for lane in range(4):
+            total += ((w >> np.uint64(16 * lane)) & np.uint64(0xFFFF)).astype(np.int64)
+    # mean of twelve U{0..65535} is 12*32767.5 = 393210; var = 12*(65536^2-1)/12
+    return ((total - 393210).astype(np.float32)) * np.float32(1.0 / 65536.0)
+
+
+def round_to_bf16(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even f32 -> bf16, returned as f32 (finite inputs only)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    with np.errstate(over="ignore"):
+        r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """bf16 bit pattern (uint16) of finite f32 values, round-to-nearest-even."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    with np.errstate(over="ignore"):
+        r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)
+    return r.astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
+def vit_tensor_specs(geom: ViTGeometry = VIT_B16):
+    """(name, shape, kind) in a fixed order; kind in {matrix, bias, gamma}."""
+    D, F, P = geom.hidden_size, geom.intermediate_size, geom.patch_size
+    specs = [
+        ("embeddings.cls_token", (1, 1, D), "matrix"),
+        ("embeddings.position_embeddings", (1, geom.seq_len, D), "matrix"),
+        ("embeddings.patch_embeddings.projection.weight", (D, geom.num_channels, P, P), "matrix"),
+        ("embeddings.patch_embeddings.projection.bias", (D,), "bias"),
+    ]
+    for i in range(geom.num_layers):
+        p = f"layers.{i}."
+        specs += [
+            (p + "layernorm_before.weight", (D,), "gamma"),
+            (p + "layernorm_before.bias", (D,), "bias"),
+            (p + "attention.q_proj.weight", (D, D), "matrix"),
+            (p + "attention.q_proj.bias", (D,), "bias"),
+            (p + "attention.k_proj.weight", (D, D), "matrix"),
+            (p + "attention.k_proj.bias", (D,), "bias"),
+            (p + "attention.v_proj.weight", (D, D), "matrix"),
+            (p + "attention.v_proj.bias", (D,), "bias"),
+            (p + "attention.o_proj.weight", (D, D), "matrix"),
+            (p + "attention.o_proj.bias", (D,), "bias"),
+            (p + "layernorm_after.weight", (D,), "gamma"),
+            (p + "layernorm_after.bias", (D,), "bias"),
+            (p + "mlp.fc1.weight", (F, D), "matrix"),
+            (p + "mlp.fc1.bias", (F,), "bias"),
+            (p + "mlp.fc2.weight", (D, F), "matrix"),
+            (p + "mlp.fc2.bias", (D,), "bias"),
+        ]
+    specs += [("layernorm.weight", (D,), "gamma"), ("layernorm.bias", (D,), "bias")]
+    return specs
+
+
+def make_vit_weights(
+    seed: int = 1,
+    geom: ViTGeometry = VIT_B16,
+    std: float = 0.02,
+    trained_like: bool = True,
+) -> dict[str, np.ndarray]:
+    """Seeded synthetic weights, f32 arrays holding bf16-representable values.
+
+    ``trained_like=False`` reproduces the Hugging Face initialiser exactly as
+    SURVEY.md §8d words it (biases 0, LayerNorm gamma 1 / beta 0).  The default
+    perturbs biases and LayerNorm parameters as well, so that every bias-add and
+    affine path of the kernels carries non-trivial data in the parity tests; the
+    arithmetic cost is identical.
+    """
+    out: dict[str, np.ndarray] = {}
+    for tid, (name, shape, kind) in enumerate(vit_tensor_specs(geom)):
+        n = int(np.prod(shape))
+        if kind == "matrix" or trained_like:
+            z = irwin_hall_normal(seed, tid, n) * np.float32(std)
+            if kind == "gamma":
+                z = z + np.float32(1.0)
+        else:
+            z = np.full(n, 1.0 if kind == "gamma" else 0.0, dtype=np.float32)
+        out[name] = round_to_bf16(z).reshape(shape)
+    return out
+
+
+def synthetic_crops(n: int, seed: int = 0, size: int = 224, start: int = 0) -> np.ndarray:
+    """uint8[n, size, size, 3] i.i.d. uniform 0..255 (SURVEY.md §8d, C2/C4 inputs).
+
+    ``start`` offsets the crop index so that a rank can generate only its shard.
+    """
+    per = size * size * 3
+    assert per % 8 == 0
+    out = np.empty((n, per), dtype=np.uint8)
+    words = per // 8
+    for k in range(n):
+        w = counter_u64(seed, 0x7000 + ((start + k) >> 16), words, (start + k) & 0xFFFF)
+        out[k] = w.view(np.uint8)
+    return out.reshape(n, size, size, 3)

@@ -1,0 +1,395 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors (run in the BUILD CONTAINER only).
+
+    python tests/golden/make_golden.py
+
+Imports the reference's own Python from /root/reference (recipe: SURVEY.md
+Appendix C.3 -- heavy optional imports are replaced by empty module objects; no
+reference source is copied) and the third-party libraries the reference
+delegates to (transformers ViT / Mllama image processor, Pillow, scikit-learn,
+scipy), runs them on seeded inputs or on the data files the reference bundles,
+and writes inputs + expected outputs as small fixtures next to this script.
+Nothing here runs on the GPU box: /root/reference does not exist there, the
+fixtures do.
+
+Fixtures written
+  report_matrix.json     19x19 page matrix (3 dp), page names, labels, k -- parsed from the
+                         reference's bundled report (a data file): KAT for cluster_images
+  region_table.json      the 19 bundled region_cache/*.json files, compacted (data files)
+  cluster_cases.npz      seeded S matrices -> labels/k/cohesion from the REAL cluster_images
+  linkage_cases.npz      seeded matrices -> scipy linkage Z, sklearn labels, silhouette
+  pagesim_cases.npz      region tables + seeded unit vectors -> S from the REAL
+                         compute_image_similarity_matrix over a brute-force collection
+  last_pooling.npz       REAL embedder.last_pooling on a seeded tensor
+  vit_cases.npz          transformers.ViTModel (seeded synthetic weights) hidden states / embeddings
+  crops/*.png            a few bundled region crops (data) incl. the 16 crops of config C1
+  crops_expected.npz     Pillow resize + MllamaImageProcessorPil outputs for those crops
+"""
+from __future__ import annotations
+
+import glob
+import hashlib
+import html
+import json
+import os
+import re
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+PKG = os.path.join(REF, "deprecated_package")
+sys.path.insert(0, REPO)
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+
+def import_reference():
+    import transformers  # noqa: F401  (before stubbing torchvision)
+
+    sys.path.insert(0, PKG)
+    for n in [
+        "chromadb",
+        "chromadb.config",
+        "chromadb.utils",
+        "chromadb.utils.embedding_functions",
+        "torchvision",
+        "cv2",
+        "pytesseract",
+        "imutils",
+    ]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["chromadb.config"].Settings = object
+    sys.modules["chromadb.utils.embedding_functions"].DefaultEmbeddingFunction = object
+    sys.modules["pytesseract"].Output = object
+    import embedder
+    import weighted_region_clustering as w
+
+    # per-pair JSON progress rewrites are O(P^4) bytes; keep them in memory
+    done = set()
+    w.is_clustering_completed = lambda key: False
+    w.mark_clustering_as_completed = lambda key: done.add(key)
+    return w, embedder
+
+
+class FakeCollection:
+    """Duck-typed exact-kNN stand-in for the chroma collection."""
+
+    def __init__(self, ids, emb, metas, metric):
+        self.ids, self.emb, self.metas, self.metric = ids, np.asarray(emb, dtype=np.float64), metas, metric
+        self.norm = self.emb / np.linalg.norm(self.emb, axis=1, keepdims=True)
+
+    def get(self, include=None, where=None, ids=None):
+        return {"ids": list(self.ids), "metadatas": list(self.metas), "embeddings": [e.tolist() for e in self.emb]}
+
+    def query(self, query_embeddings, n_results, include=None, where=None):
+        q = np.asarray(query_embeddings[0], dtype=np.float64)
+        q = q / np.linalg.norm(q)
+        (key, cond), = where.items()
+        rows = np.array([i for i, m in enumerate(self.metas) if m.get(key) == cond["$eq"]], dtype=np.int64)
+        cos = self.norm[rows] @ q
+        d = 1.0 - cos if self.metric == "cosine" else 2.0 - 2.0 * cos
+        order = np.argsort(d, kind="stable")[:n_results]
+        return {
+            "ids": [[self.ids[rows[k]] for k in order]],
+            "distances": [[float(d[k]) for k in order]],
+            "metadatas": [[self.metas[rows[k]] for k in order]],
+            "documents": [[None for _ in order]],
+        }
+
+
+def parse_report():
+    path = os.path.join(PKG, "output/weighted_clustering/html_report/index.html")
+    txt = open(path, encoding="utf-8").read()
+    lines = txt.split("\n")
+    k = int(re.search(r"Number of clusters: (\d+)", txt).group(1))
+    # clusters
+    membership = {}
+    for m in re.finditer(r"<h3>Cluster (\d+)</h3>(.*?)</table>", txt, flags=re.S):
+        lab = int(m.group(1))
+        for nm in re.findall(r"<td>(.*?)</td>", m.group(2)):
+            membership[html.unescape(nm)] = lab
+    names = sorted(membership)
+    row = lines[602]
+    cells = re.findall(r"<td[^>]*>([0-9.]+)</td>", row)
+    P = len(names)
+    assert len(cells) == P * P, (len(cells), P)
+    M = np.array([float(c) for c in cells]).reshape(P, P)
+    labels = [membership[n] for n in names]
+    top = []
+    sec = txt[txt.index("<h2>Top Similarities</h2>") :]
+    sec = sec[: sec.index("</table>")]
+    for a, b, v in re.findall(r"<td>(.*?)</td>\s*<td>(.*?)</td>\s*<td>([0-9.]+)</td>", sec, flags=re.S):
+        top.append([names.index(html.unescape(a)), names.index(html.unescape(b)), float(v)])
+    return {"names": names, "matrix": M.tolist(), "labels": labels, "n_clusters": k, "top_pairs": top}
+
+
+def load_region_table():
+    pages = []
+    for f in sorted(glob.glob(os.path.join(PKG, "output/region_cache/*.json"))):
+        d = json.load(open(f))
+        stem = os.path.basename(f).replace("_conf0.1_iou0.45.json", "")
+        pages.append(
+            {
+                "name": stem + ".png",
+                "width": d["image_size"]["width"],
+                "height": d["image_size"]["height"],
+                "boxes": d["boxes"],
+                "classes": d["classes"],
+                "scores": d["scores"],
+                "class_names": d["class_names"],
+            }
+        )
+    pages.sort(key=lambda p: p["name"])
+    return pages
+
+
+def table_rows(pages):
+    """Rows as region_processor.py:75-113 would upsert them (type filter, int box, area %)."""
+    from oracle.compare import REGION_TYPES_TO_PROCESS
+
+    ids, metas, page_of = [], [], []
+    for pi, p in enumerate(pages):
+        for i, (box, cname) in enumerate(zip(p["boxes"], p["class_names"])):
+            if cname not in REGION_TYPES_TO_PROCESS:
+                continue
+            x0, y0, x1, y1 = map(int, box)
+            tot = p["width"] * p["height"]
+            ap = ((x1 - x0) * (y1 - y0) / tot) * 100 if tot else 0
+            ids.append(f"region_{os.path.splitext(p['name'])[0]}_{i}")
+            metas.append({"parent_image_name": p["name"], "region_type": cname, "area_percentage": ap, "is_region": True})
+            page_of.append(pi)
+    return ids, metas, np.array(page_of)
+
+
+def unit_vectors(n, d, seed, clusters=0):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((n, d))
+    if clusters:
+        c = rng.standard_normal((clusters, d)) * 2.0
+        v = v + c[rng.integers(0, clusters, n)]
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    return v.astype(np.float32)
+
+
+def main():
+    scratch = tempfile.mkdtemp(prefix="golden_")
+    os.chdir(scratch)
+    os.makedirs("output", exist_ok=True)
+    w, ref_embedder = import_reference()
+    import torch
+
+    # ---- 1. report KAT -------------------------------------------------------------
+    rep = parse_report()
+    M = np.array(rep["matrix"])
+    res = w.cluster_images(M.copy(), list(rep["names"]))
+    assert res["labels"] == rep["labels"], (res["labels"], rep["labels"])
+    assert res["n_clusters"] == rep["n_clusters"]
+    rep["cohesion"] = {str(k): v for k, v in res["cluster_cohesion"].items()}
+    json.dump(rep, open(os.path.join(HERE, "report_matrix.json"), "w"))
+    print("report KAT ok: labels", res["labels"])
+
+    # ---- 2. region table ----------------------------------------------------------
+    pages = load_region_table()
+    json.dump(pages, open(os.path.join(HERE, "region_table.json"), "w"), separators=(",", ":"))
+    ids, metas, page_of = table_rows(pages)
+    assert len(ids) == 1867, len(ids)
+    progress = json.load(open(os.path.join(PKG, "output/region_embedding_progress.json")))
+    key = next(iter(progress))
+    assert sorted(progress[key]) == sorted(ids), "region ids differ from the reference's progress file"
+
+    # ---- 3. cluster_images on seeded matrices ---------------------------------------
+    from scipy.cluster import hierarchy
+    from sklearn.cluster import AgglomerativeClustering
+    from sklearn.metrics import silhouette_score
+
+    cc, lc = {}, {}
+    rng = np.random.default_rng(1234)
+    case = 0
+    for P, kind in [(2, "dense"), (3, "dense"), (5, "dense"), (8, "sparse"), (10, "dense"), (12, "blocks"), (19, "sparse"), (40, "blocks"), (64, "dense"), (7, "few")]:
+        A = rng.random((P, P))
+        S = (A + A.T) / 2
+        if kind == "sparse":
+            S[rng.random((P, P)) < 0.6] = 0
+            S = np.maximum(S, S.T) * (S > 0) * (S.T > 0)
+        if kind == "blocks":
+            g = rng.integers(0, 4, P)
+            S = S * 0.2 + 0.7 * (g[:, None] == g[None, :])
+        if kind == "few":
+            S = np.zeros((P, P))
+            S[0, 1] = S[1, 0] = 1.0
+            S[2, 3] = S[3, 2] = 0.4
+        mx = np.max(S - np.diag(np.diag(S)))
+        S = S / mx
+        np.fill_diagonal(S, 1.0)
+        names = [f"page_{i:03d}.png" for i in range(P)]
+        for fixed in (None, 3 if P >= 3 else 2):
+            r = w.cluster_images(S.copy(), names, n_clusters=fixed)
+            if r is None:
+                # the reference returns None when sklearn raises (e.g. k > P); record that too
+                cc[f"c{case}_S"] = S
+                cc[f"c{case}_fixed"] = np.array(-1 if fixed is None else fixed)
+                cc[f"c{case}_none"] = np.array(1)
+                case += 1
+                continue
+            cc[f"c{case}_S"] = S
+            cc[f"c{case}_fixed"] = np.array(-1 if fixed is None else fixed)
+            cc[f"c{case}_labels"] = np.array(r["labels"])
+            cc[f"c{case}_k"] = np.array(r["n_clusters"])
+            cc[f"c{case}_coh_keys"] = np.array(sorted(r["cluster_cohesion"]))
+            cc[f"c{case}_coh_vals"] = np.array([r["cluster_cohesion"][k] for k in sorted(r["cluster_cohesion"])])
+            case += 1
+        if P >= 3:
+            D = 1.0 - S
+            Z = hierarchy.linkage(D, method="average", metric="euclidean")
+            lc[f"l{P}_{kind}_D"] = D
+            lc[f"l{P}_{kind}_Z"] = Z
+            Zp = hierarchy.linkage(D[np.triu_indices(P, 1)], method="average")
+            lc[f"l{P}_{kind}_Zpre"] = Zp
+            for k in range(2, min(10, P) + 1):
+                lab = AgglomerativeClustering(n_clusters=k, linkage="average").fit(D).labels_
+                lc[f"l{P}_{kind}_lab{k}"] = lab
+                if 1 < len(np.unique(lab)) < P:
+                    lc[f"l{P}_{kind}_sil{k}"] = np.array(silhouette_score(D, lab, metric="precomputed"))
+                labp = AgglomerativeClustering(n_clusters=k, linkage="average", metric="precomputed").fit(D).labels_
+                lc[f"l{P}_{kind}_labpre{k}"] = labp
+    cc["n_cases"] = np.array(case)
+    np.savez_compressed(os.path.join(HERE, "cluster_cases.npz"), **cc)
+    np.savez_compressed(os.path.join(HERE, "linkage_cases.npz"), **lc)
+    print("cluster cases:", case)
+
+    # ---- 4. compute_image_similarity_matrix over a brute-force collection -----------
+    pc = {}
+    names19 = [p["name"] for p in pages]
+    paths19 = ["/somewhere/" + n for n in names19]
+    emb = unit_vectors(len(ids), 64, 7, clusters=12)
+    pc["real_emb"] = emb
+    pc["real_area_percentage"] = np.array([m["area_percentage"] for m in metas])
+    pc["real_page_of"] = page_of
+    for metric in ("cosine", "sqeuclidean"):
+        S, nm = w.compute_image_similarity_matrix(FakeCollection(ids, emb, metas, metric), paths19)
+        assert nm == names19
+        pc[f"real_S_{metric}"] = S
+    # the zero pattern of the bundled report must reappear (same-prefix skips)
+    Z = np.array(rep["matrix"]) == 0
+    assert np.array_equal(pc["real_S_cosine"][Z], np.zeros(Z.sum())), "same-prefix zero pattern differs"
+    S_np, _ = w.compute_image_similarity_matrix(FakeCollection(ids, emb, metas, "cosine"), paths19, skip_same_prefix=False)
+    pc["real_S_cosine_noskip"] = S_np
+
+    # synthetic table with edge cases: empty page, zero-area rows, <10 regions, foreign types
+    rng = np.random.default_rng(99)
+    P = 9
+    syn_names = [f"{'Same Prefix Newspaper Title':<20}{i}.png" if i in (2, 3) else f"Paper {i:02d} of the synthetic set.png" for i in range(P)]
+    counts = [14, 3, 25, 11, 0, 1, 40, 12, 7]
+    s_ids, s_metas, s_page = [], [], []
+    for p, c in enumerate(counts):
+        for r in range(c):
+            ap = float(np.exp(rng.uniform(np.log(1e-2), np.log(20.0))))
+            if rng.random() < 0.08:
+                ap = 0.0
+            typ = "plain_text" if rng.random() > 0.05 else "abandon"
+            s_ids.append(f"region_p{p}_{r}")
+            s_metas.append({"parent_image_name": syn_names[p], "region_type": typ, "area_percentage": ap, "is_region": True})
+            s_page.append(p)
+    s_emb = unit_vectors(len(s_ids), 32, 5, clusters=5)
+    # exact duplicate vectors to exercise tie ordering
+    s_emb[20] = s_emb[21]
+    s_emb[70] = s_emb[71] = s_emb[72]
+    pc["syn_emb"] = s_emb
+    pc["syn_area_percentage"] = np.array([m["area_percentage"] for m in s_metas])
+    pc["syn_page_of"] = np.array(s_page)
+    pc["syn_types_ok"] = np.array([m["region_type"] == "plain_text" for m in s_metas])
+    json.dump({"names": syn_names}, open(os.path.join(HERE, "pagesim_names.json"), "w"))
+    for metric in ("cosine", "sqeuclidean"):
+        S, nm = w.compute_image_similarity_matrix(FakeCollection(s_ids, s_emb, s_metas, metric), ["/x/" + n for n in syn_names])
+        pc[f"syn_S_{metric}"] = S
+    np.savez_compressed(os.path.join(HERE, "pagesim_cases.npz"), **pc)
+    print("pagesim cases ok")
+
+    # ---- 5. last_pooling -------------------------------------------------------------
+    g = torch.Generator().manual_seed(3)
+    hs = torch.randn(5, 9, 16, generator=g)
+    mask = torch.tensor([[1] * 9, [1] * 4 + [0] * 5, [1] + [0] * 8, [1] * 7 + [0] * 2, [1] * 2 + [0] * 7])
+    out = ref_embedder.last_pooling(hs, mask)
+    out_raw = ref_embedder.last_pooling(hs, mask, normalize=False)
+    np.savez_compressed(os.path.join(HERE, "last_pooling.npz"), hs=hs.numpy(), mask=mask.numpy(), out=out.numpy(), out_raw=out_raw.numpy())
+
+    # ---- 6. transformers ViT with the seeded synthetic weights -------------------------
+    from transformers import ViTConfig, ViTModel
+
+    from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops
+    from oracle.preprocess import patchify, preprocess_crop
+    from oracle.vit import vit_embed, vit_hidden_states
+
+    vc = {}
+    for tag, std in (("std002", 0.02), ("std008", 0.08)):
+        wts = make_vit_weights(seed=1, std=std)
+        model = ViTModel(ViTConfig(), add_pooling_layer=False).eval()
+        sd = {k: torch.from_numpy(v.copy()) for k, v in wts.items()}
+        missing = model.load_state_dict(sd, strict=True)
+        crops = synthetic_crops(3, seed=0)
+        px = np.stack([preprocess_crop(c) for c in crops])
+        with torch.no_grad():
+            hf = model(pixel_values=torch.from_numpy(px)).last_hidden_state.numpy()
+        mine = vit_hidden_states(torch.from_numpy(np.stack([patchify(p) for p in px])), wts).numpy()
+        err = np.abs(hf - mine).max()
+        print(tag, "oracle vs transformers ViTModel max abs err", err)
+        assert err < 2e-4, err
+        cls = hf[:, 0] / np.linalg.norm(hf[:, 0], axis=1, keepdims=True)
+        last = hf[:, -1] / np.linalg.norm(hf[:, -1], axis=1, keepdims=True)
+        vc[f"{tag}_cls"] = cls.astype(np.float32)
+        vc[f"{tag}_last"] = last.astype(np.float32)
+        vc[f"{tag}_hidden_sample"] = hf[:, ::49, ::64].astype(np.float32)
+    vc["crop_seed"] = np.array(0)
+    vc["n"] = np.array(3)
+    np.savez_compressed(os.path.join(HERE, "vit_cases.npz"), **vc)
+
+    # ---- 7. real crops through Pillow + the Mllama image processor ----------------------
+    from PIL import Image
+    from transformers.models.mllama.image_processing_pil_mllama import MllamaImageProcessorPil
+
+    from oracle.preprocess import CLIP_MEAN, CLIP_STD, fit_to_canvas
+
+    crop_dir = os.path.join(PKG, "output/region_images")
+    allf = sorted(os.listdir(crop_dir))
+    sizes = {f: Image.open(os.path.join(crop_dir, f)).size for f in allf}
+    c1_page = "Addision NY Advertiser 1883-1887 - 0001.pdf_387d113864_page_0000"
+    c1 = sorted([f for f in allf if f.startswith(c1_page)], key=lambda f: int(re.search(r"_region(\d+)_", f).group(1)))[:16]
+    small = [f for f in allf if os.path.getsize(os.path.join(crop_dir, f)) < 120_000]
+    by_aspect = sorted(small, key=lambda f: sizes[f][0] / sizes[f][1])
+    by_area = sorted(small, key=lambda f: sizes[f][0] * sizes[f][1])
+    extra = [by_aspect[0], by_aspect[1], by_aspect[-1], by_aspect[-2], by_area[0], by_area[1], by_area[-1], by_aspect[len(by_aspect) // 2]]
+    picked = c1 + [f for f in extra if f not in c1]
+    out_dir = os.path.join(HERE, "crops")
+    shutil.rmtree(out_dir, ignore_errors=True)
+    os.makedirs(out_dir)
+    proc = MllamaImageProcessorPil(size={"height": 224, "width": 224}, max_image_tiles=1, image_mean=list(CLIP_MEAN), image_std=list(CLIP_STD))
+    ce = {}
+    manifest = []
+    for i, f in enumerate(picked):
+        shutil.copyfile(os.path.join(crop_dir, f), os.path.join(out_dir, f))
+        os.chmod(os.path.join(out_dir, f), 0o644)
+        im = Image.open(os.path.join(crop_dir, f))
+        wd, ht = im.size
+        nh, nw = fit_to_canvas(ht, wd)
+        rs = np.array(im.convert("RGB").resize((nw, nh), resample=Image.BILINEAR))
+        pv = proc(images=[im], return_tensors="np")["pixel_values"][0, 0, 0]
+        ce[f"resized_{i}"] = rs
+        ce[f"pv_sha256_{i}"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(pv).tobytes()).digest(), dtype=np.uint8)
+        ce[f"pv_sample_{i}"] = pv[:, ::7, ::5].copy()
+        manifest.append({"file": f, "width": wd, "height": ht, "new_h": nh, "new_w": nw})
+    json.dump({"c1_count": len(c1), "crops": manifest}, open(os.path.join(HERE, "crops_manifest.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "crops_expected.npz"), **ce)
+    # crop sizes of the whole bundled set (for the C3 workload shape): int-truncated bbox sizes
+    all_sizes = np.array([[sizes[f][1], sizes[f][0]] for f in allf], dtype=np.int32)
+    np.save(os.path.join(HERE, "bundled_crop_sizes_hw.npy"), all_sizes)
+    print("crops:", len(picked), "fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

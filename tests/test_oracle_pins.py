@@ -1,0 +1,187 @@
+"""The oracle is only trusted once it reproduces every golden vector (tier rule 3).
+
+Goldens come from tests/golden/make_golden.py: the reference's own functions
+(cluster_images, compute_image_similarity_matrix, last_pooling), its bundled report
+and data files, and the third-party code it delegates to (transformers ViT / Mllama
+image processor, Pillow, scipy, scikit-learn).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops
+from oracle import cluster as oc
+from oracle import compare as ocmp
+from oracle import preprocess as opre
+from oracle import vit as ovit
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_report_kat_labels(golden_dir):
+    rep = json.load(open(os.path.join(golden_dir, "report_matrix.json")))
+    M = np.array(rep["matrix"])
+    res = oc.cluster_images(M.copy(), list(rep["names"]))
+    assert res["n_clusters"] == rep["n_clusters"] == 10
+    assert res["labels"] == rep["labels"] == [7, 9, 0, 5, 0, 4, 0, 0, 0, 0, 2, 2, 2, 8, 0, 3, 6, 0, 1]
+    for k, v in rep["cohesion"].items():
+        assert res["cluster_cohesion"][int(k)] == pytest.approx(v, abs=1e-15)
+    # fallback-path silhouettes for k=2..10
+    D = 1.0 - M
+    np.fill_diagonal(D, 0.0)
+    want = [-0.2596, -0.2582, -0.2045, -0.1714, -0.1720, -0.1716, -0.1430, -0.1420, -0.1250]
+    got = [oc.silhouette_precomputed(D, oc.agglomerative_labels(D, k)) for k in range(2, 11)]
+    assert np.allclose(got, want, atol=5e-5)
+    # precomputed mode gives the OTHER labelling the survey probed (G3)
+    pre = oc.cluster_images(M.copy(), list(rep["names"]), mode="precomputed")
+    assert pre["labels"] != rep["labels"]
+
+
+def test_cluster_cases_match_reference(golden_dir):
+    g = _load(golden_dir, "cluster_cases.npz")
+    n = int(g["n_cases"])
+    assert n >= 15
+    for c in range(n):
+        S = g[f"c{c}_S"]
+        fixed = int(g[f"c{c}_fixed"])
+        names = [f"page_{i:03d}.png" for i in range(S.shape[0])]
+        if f"c{c}_none" in g:
+            with pytest.raises(Exception):
+                r = oc.cluster_images(S.copy(), names, n_clusters=None if fixed < 0 else fixed)
+                assert r is not None
+            continue
+        r = oc.cluster_images(S.copy(), names, n_clusters=None if fixed < 0 else fixed)
+        assert r["labels"] == g[f"c{c}_labels"].tolist(), c
+        assert r["n_clusters"] == int(g[f"c{c}_k"]), c
+        keys = g[f"c{c}_coh_keys"].tolist()
+        assert sorted(r["cluster_cohesion"]) == keys
+        assert np.allclose([r["cluster_cohesion"][k] for k in keys], g[f"c{c}_coh_vals"], rtol=0, atol=1e-15)
+
+
+def test_linkage_matches_scipy_and_sklearn(golden_dir):
+    g = _load(golden_dir, "linkage_cases.npz")
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_D")})
+    assert tags
+    for t in tags:
+        D = g[t + "_D"]
+        P = D.shape[0]
+        Z = oc.linkage_average(oc.pdist_rows_euclidean(D), P)
+        assert np.array_equal(Z[:, :2], g[t + "_Z"][:, :2]), t
+        assert np.allclose(Z[:, 2], g[t + "_Z"][:, 2], rtol=1e-15, atol=0), t
+        assert np.array_equal(Z[:, 3], g[t + "_Z"][:, 3]), t
+        Zp = oc.linkage_average(oc.squareform_to_condensed(D), P)
+        assert np.array_equal(Zp[:, :2], g[t + "_Zpre"][:, :2]), t
+        for k in range(2, min(10, P) + 1):
+            assert np.array_equal(oc.agglomerative_labels(D, k), g[f"{t}_lab{k}"]), (t, k)
+            assert np.array_equal(oc.agglomerative_labels(D, k, "precomputed"), g[f"{t}_labpre{k}"]), (t, k)
+            if f"{t}_sil{k}" in g:
+                assert oc.silhouette_precomputed(D, g[f"{t}_lab{k}"]) == pytest.approx(float(g[f"{t}_sil{k}"]), abs=1e-14)
+
+
+def test_pagesim_matches_reference(golden_dir):
+    g = _load(golden_dir, "pagesim_cases.npz")
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    names = [p["name"] for p in pages]
+    for metric in ("cosine", "sqeuclidean"):
+        S, nm = ocmp.compute_image_similarity_matrix(g["real_emb"], g["real_area_percentage"], g["real_page_of"], names, metric=metric)
+        assert nm == names
+        assert np.allclose(S, g[f"real_S_{metric}"], rtol=1e-12, atol=1e-15)
+    S, _ = ocmp.compute_image_similarity_matrix(g["real_emb"], g["real_area_percentage"], g["real_page_of"], names, skip_same_prefix=False)
+    assert np.allclose(S, g["real_S_cosine_noskip"], rtol=1e-12, atol=1e-15)
+    syn_names = json.load(open(os.path.join(golden_dir, "pagesim_names.json")))["names"]
+    types = ["plain_text" if ok else "abandon" for ok in g["syn_types_ok"]]
+    for metric in ("cosine", "sqeuclidean"):
+        S, _ = ocmp.compute_image_similarity_matrix(g["syn_emb"], g["syn_area_percentage"], g["syn_page_of"], syn_names, types, metric=metric)
+        assert np.allclose(S, g[f"syn_S_{metric}"], rtol=1e-12, atol=1e-15)
+        assert S[2, 3] == 0 and S[4].sum() == 1.0  # same-prefix pair skipped, empty page only has its diagonal
+
+
+def test_pagesim_empty_table():
+    assert ocmp.compute_image_similarity_matrix(np.zeros((0, 8)), np.zeros(0), np.zeros(0, dtype=int), ["a", "b"]) == (None, None)
+
+
+def test_region_table_counts(golden_dir):
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    assert len(pages) == 19
+    nbox = sum(len(p["boxes"]) for p in pages)
+    nemb = sum(sum(c in ocmp.REGION_TYPES_TO_PROCESS for c in p["class_names"]) for p in pages)
+    assert (nbox, nemb) == (1938, 1867)
+    for p in pages:  # detector-score order (G6)
+        assert all(a >= b for a, b in zip(p["scores"], p["scores"][1:]))
+
+
+def test_last_pooling_matches_reference(golden_dir):
+    g = _load(golden_dir, "last_pooling.npz")
+    hs, mask = torch.from_numpy(g["hs"]), torch.from_numpy(g["mask"])
+    assert np.array_equal(ovit.last_pooling(hs, mask).numpy(), g["out"])
+    assert np.array_equal(ovit.last_pooling(hs, mask, normalize=False).numpy(), g["out_raw"])
+
+
+def test_vit_matches_transformers(golden_dir):
+    g = _load(golden_dir, "vit_cases.npz")
+    crops = synthetic_crops(int(g["n"]), seed=int(g["crop_seed"]))
+    patches = np.stack([opre.preprocess_to_patches(c) for c in crops])
+    for tag, std in (("std002", 0.02), ("std008", 0.08)):
+        w = make_vit_weights(seed=1, std=std)
+        hs = ovit.vit_hidden_states(torch.from_numpy(patches), w).numpy()
+        assert np.abs(hs[:, ::49, ::64] - g[f"{tag}_hidden_sample"]).max() < 2e-4
+        for pool in ("cls", "last"):
+            e = ovit.vit_embed(patches, w, pool=pool)
+            cos = np.sum(e * g[f"{tag}_{pool}"], axis=1)
+            assert np.all(1.0 - cos < 1e-6), (tag, pool, cos)
+
+
+def test_preprocess_matches_pillow_and_mllama_processor(golden_dir):
+    from PIL import Image
+
+    man = json.load(open(os.path.join(golden_dir, "crops_manifest.json")))
+    g = _load(golden_dir, "crops_expected.npz")
+    assert man["c1_count"] == 16
+    for i, c in enumerate(man["crops"]):
+        img = np.array(Image.open(os.path.join(golden_dir, "crops", c["file"])).convert("RGB"))
+        assert img.shape[:2] == (c["height"], c["width"])
+        assert opre.fit_to_canvas(c["height"], c["width"]) == (c["new_h"], c["new_w"])
+        rs = opre.pil_bilinear_resize_u8(img, c["new_h"], c["new_w"])
+        assert np.array_equal(rs, g[f"resized_{i}"]), c["file"]
+        pv = opre.preprocess_crop(img)
+        assert np.array_equal(pv[:, ::7, ::5], g[f"pv_sample_{i}"])
+        sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(pv).tobytes()).digest(), dtype=np.uint8)
+        assert np.array_equal(sha, g[f"pv_sha256_{i}"]), c["file"]
+
+
+def test_resize_matches_live_pillow_on_synthetic_shapes():
+    """Pillow is in the image on both boxes: compare live on shapes the fixtures do not hold."""
+    from PIL import Image
+
+    rng = np.random.default_rng(5)
+    for h, w in [(20, 63), (5114, 60), (37, 3862), (224, 224), (223, 225), (1, 500), (300, 1), (448, 448), (100, 100), (1000, 333)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        nh, nw = opre.fit_to_canvas(h, w)
+        ref = np.array(Image.fromarray(img).resize((nw, nh), resample=Image.BILINEAR))
+        assert np.array_equal(opre.pil_bilinear_resize_u8(img, nh, nw), ref), (h, w)
+
+
+@pytest.mark.reference
+def test_bundled_crop_sizes_equal_int_bbox(golden_dir):
+    """every bundled crop's pixel size equals the int()-truncated bbox."""
+    from PIL import Image
+
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    crop_dir = "/root/reference/deprecated_package/output/region_images"
+    checked = 0
+    for p in pages:
+        stem = os.path.splitext(p["name"])[0]
+        for i, (box, cname) in enumerate(zip(p["boxes"], p["class_names"])):
+            f = os.path.join(crop_dir, f"{stem}_region{i}_{cname}.png")
+            if not os.path.exists(f):
+                continue
+            x0, y0, x1, y1 = opre.crop_box_int(box)
+            assert Image.open(f).size == (x1 - x0, y1 - y0)
+            checked += 1
+    assert checked == 1862
