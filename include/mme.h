@@ -1,0 +1,158 @@
+/* mme.h -- C ABI of the MI355X-native region embed -> compare -> page-cluster engine.
+ *
+ * The reference (calhounpaul/multimodal_embeddings) has no FFI: its hot path is two
+ * duck-typed Python objects (an `embedder` and a vector-store `collection`) plus two
+ * free functions.  This header is the boundary a maintainer binds with
+ * ctypes (INTEGRATION.md shows the stub); each entry point cites the reference
+ * interface it replaces.  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - one mme_ctx per GPU / per process rank; not thread-safe (use one ctx per thread);
+ *   - every function returns 0 on success or a negative MME_E_* code and never throws;
+ *     mme_last_error(ctx) returns the message of the last failure;
+ *   - "dev" pointers are device (HBM) pointers owned by the caller, "host" pointers are
+ *     ordinary host memory; all launches are asynchronous on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream) unless the name ends in _sync;
+ *   - bf16 = 16-bit brain float stored as uint16_t.
+ */
+#ifndef MME_H
+#define MME_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MME_ABI_VERSION 1
+
+enum {
+    MME_OK = 0,
+    MME_E_ARG = -1,     /* bad argument (null pointer, size, alignment) */
+    MME_E_STATE = -2,   /* call order (e.g. forward before load) */
+    MME_E_HIP = -3,     /* HIP runtime / launch failure */
+    MME_E_NOMEM = -4
+};
+
+typedef struct mme_ctx mme_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------
+ * Replaces MmE5MllamaEmbedder.__init__'s per-device replica set-up
+ * (deprecated_package/embedder.py:42-84): one context per visible GPU. */
+int mme_abi_version(void);
+int mme_create(int device, mme_ctx** out);
+void mme_destroy(mme_ctx* ctx);
+const char* mme_last_error(const mme_ctx* ctx); /* ctx may be NULL: creation errors */
+
+/* ---- encoder weights --------------------------------------------------------------
+ * Replaces `MllamaForConditionalGeneration.from_pretrained(...)` (embedder.py:75-80) for
+ * the re-scoped ViT-B/16 encoder.  Host f32 tensors in Hugging Face ViT layout
+ * (transformers models/vit/modeling_vit.py): Linear weights are [out, in]; the patch
+ * projection is [hidden, 3*patch*patch] in (c, ky, kx) order.  Values are rounded to
+ * bf16 on upload (the reference runs the encoder in bf16, embedder.py:78). */
+typedef struct {
+    const float *ln1_g, *ln1_b;
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *o_w, *o_b;
+    const float *ln2_g, *ln2_b;
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} mme_vit_layer;
+
+typedef struct {
+    int32_t image_size;  /* 224 */
+    int32_t patch_size;  /* 16  */
+    int32_t hidden;      /* 768 */
+    int32_t layers;      /* 12  */
+    int32_t heads;       /* 12  */
+    int32_t mlp;         /* 3072 */
+    float ln_eps;        /* 1e-12 */
+    const float* cls_token; /* [hidden] */
+    const float* pos_emb;   /* [1 + (image/patch)^2, hidden] */
+    const float* patch_w;   /* [hidden, 3*patch*patch] */
+    const float* patch_b;   /* [hidden] */
+    const float* lnf_g;     /* final LayerNorm */
+    const float* lnf_b;
+    const mme_vit_layer* layer; /* [layers] */
+} mme_vit_weights;
+
+int mme_load_vit(mme_ctx* ctx, const mme_vit_weights* w);
+
+/* Pixel normalisation constants of the image processor (per channel; default CLIP).
+ * Replaces the `image_mean` / `image_std` of the checkpoint's preprocessor_config. */
+int mme_set_normalisation(mme_ctx* ctx, const float mean[3], const float std[3]);
+
+/* Rows of the internal activation workspace = crops per encoder pass (default 1024). */
+int mme_set_chunk(mme_ctx* ctx, int crops_per_pass);
+
+/* ---- K1: crop -> resize -> pad -> normalise -> patchify ------------------------------
+ * Replaces, per crop, `processor(images=[image])` (embedder.py:117-121; transformers
+ * image_processing_pil_mllama.py:483-541 with tile 224, one tile): aspect-preserving
+ * Pillow-BILINEAR fit (bit-exact incl. the per-pass uint8 rounding), zero pad right/
+ * bottom BEFORE normalisation, x/255, (x-mean)/std, im2col to [196, 768] in (c,ky,kx).
+ *   pix_dev     uint8 RGB HWC pixels of all crops, concatenated; the allocation must
+ *               extend at least 16 bytes past the last pixel (rows are read in words)
+ *   offs_host   int64[n]   byte offset of crop i inside pix_dev
+ *   hw_host     int32[n,2] (height, width) of crop i  (int()-truncated bbox size,
+ *                          doclayout_detector.py:179)
+ *   patches_dev bf16[n*196, 768] */
+int mme_preprocess(mme_ctx* ctx, const uint8_t* pix_dev, const int64_t* offs_host, const int32_t* hw_host,
+                   int n, uint16_t* patches_dev, void* stream);
+
+/* ---- K2-K8: ViT forward + pool + L2 normalise -------------------------------------------
+ * Replaces `model(**inputs, output_hidden_states=True)` + `last_pooling`
+ * (embedder.py:124-129, :17-34).  pool_token: 0 = [CLS] (default), 196 = last token
+ * (the reference's "last attended token" with an all-ones mask), any 0..196.
+ *   emb_f32_dev  float[n, hidden]  L2-normalised (may be NULL)
+ *   emb_bf16_dev bf16 [n, hidden]  same vectors rounded to bf16 (may be NULL) */
+int mme_vit_forward(mme_ctx* ctx, const uint16_t* patches_dev, int n, int pool_token,
+                    float* emb_f32_dev, uint16_t* emb_bf16_dev, void* stream);
+
+/* K1 + K2-K8 in one call, chunked through the internal workspace.  This is the device
+ * side of `get_image_embeddings` (embedder.py:141-226) for decoded crops. */
+int mme_embed(mme_ctx* ctx, const uint8_t* pix_dev, const int64_t* offs_host, const int32_t* hw_host,
+              int n, int pool_token, float* emb_f32_dev, uint16_t* emb_bf16_dev, void* stream);
+
+/* f32 vectors (the reference moves embeddings as Python float lists, embedder.py:132) ->
+ * L2-normalised bf16 rows, same normalisation as last_pooling (F.normalize, eps 1e-12).
+ * x_dev float[rows,d] (d % 4 == 0, 16-byte aligned rows), y_dev bf16[rows,d]. */
+int mme_normalise_rows(mme_ctx* ctx, const float* x_dev, int64_t rows, int d, uint16_t* y_dev, void* stream);
+
+/* ---- K9: all-pairs cosine ---------------------------------------------------------------
+ * The exact object every `collection.query` of the reference samples from
+ * (weighted_region_clustering.py:79-84, region_compare.py:165-170,
+ * cross_compare.py:119-123): sim[i,j] = <a_i, b_j> over L2-normalised bf16 rows,
+ * f32 accumulate.  a [m,d], b [n,d] row-major, d % 64 == 0; sim f32 row-major with
+ * leading dimension ld_sim >= n. */
+int mme_cosine(mme_ctx* ctx, const uint16_t* a_dev, int m, const uint16_t* b_dev, int n, int d,
+               float* sim_dev, int64_t ld_sim, void* stream);
+
+/* ---- K10: segmented top-k + area-weighted page reduction ---------------------------------
+ * Replaces the page-pair loop of compute_image_similarity_matrix
+ * (weighted_region_clustering.py:162-252).  Regions are grouped by page:
+ * rows page_offs[p] .. page_offs[p+1]-1 of emb belong to page p, in collection order.
+ *   emb_dev        bf16[N, d] L2-normalised region vectors
+ *   area_pct_dev   double[N]  area_percentage (0-100) as stored (region_processor.py:89-93)
+ *   valid_dev      uint8[N]   1 = area>0 and type in REGION_TYPES_TO_PROCESS (wrc:136)
+ *   page_offs_host int32[P+1]
+ *   skip_dev       uint8[P,P] 1 = pair skipped (same 20-char prefix, wrc:179-186); may be NULL
+ *   max_query      10 (wrc:199), top_k 10 (wrc:210), max_dist 0.9 (wrc:223)
+ *   metric         0: d = 1-cos, 1: d = 2-2cos
+ *   normalise      1: divide off-diagonal by its max, diagonal = 1 (wrc:246-252)
+ *   S_dev          double[P,P] */
+int mme_page_similarity(mme_ctx* ctx, const uint16_t* emb_dev, int64_t N, int d, const double* area_pct_dev,
+                        const uint8_t* valid_dev, const int32_t* page_offs_host, int P, const uint8_t* skip_dev,
+                        int max_query, int top_k, double max_dist, int metric, int normalise, double* S_dev,
+                        void* stream);
+
+/* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
+ * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce */
+#define MME_NUM_KERNEL_CLASSES 8
+int mme_profile_enable(mme_ctx* ctx, int on);
+int mme_profile_reset(mme_ctx* ctx);
+/* synchronises the recorded events; ms[c] = total ms, launches[c] = launch count per class */
+int mme_profile_read_sync(mme_ctx* ctx, double ms[MME_NUM_KERNEL_CLASSES], int64_t launches[MME_NUM_KERNEL_CLASSES]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MME_H */

@@ -1,0 +1,242 @@
+"""ctypes binding of libmme.so (include/mme.h).  Fails loudly: there is no CPU fallback.
+
+Only this module touches the C ABI; the host mirrors of the reference interface
+(embedder.py, cross_compare.py, weighted_region_clustering.py) go through `Engine`.
+torch is used for device memory and streams only (data_ptr() into the ABI).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmme.so")
+
+NUM_KERNEL_CLASSES = 8
+KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "reserved")
+
+
+class MmeError(RuntimeError):
+    pass
+
+
+class _Layer(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in (
+        "ln1_g", "ln1_b", "q_w", "q_b", "k_w", "k_b", "v_w", "v_b", "o_w", "o_b",
+        "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class _Weights(C.Structure):
+    _fields_ = [
+        ("image_size", C.c_int32), ("patch_size", C.c_int32), ("hidden", C.c_int32), ("layers", C.c_int32),
+        ("heads", C.c_int32), ("mlp", C.c_int32), ("ln_eps", C.c_float),
+        ("cls_token", C.POINTER(C.c_float)), ("pos_emb", C.POINTER(C.c_float)),
+        ("patch_w", C.POINTER(C.c_float)), ("patch_b", C.POINTER(C.c_float)),
+        ("lnf_g", C.POINTER(C.c_float)), ("lnf_b", C.POINTER(C.c_float)),
+        ("layer", C.POINTER(_Layer)),
+    ]
+
+
+EXPORTS = {
+    "mme_abi_version": (C.c_int, []),
+    "mme_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "mme_destroy": (None, [C.c_void_p]),
+    "mme_last_error": (C.c_char_p, [C.c_void_p]),
+    "mme_load_vit": (C.c_int, [C.c_void_p, C.POINTER(_Weights)]),
+    "mme_set_normalisation": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mme_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "mme_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_normalise_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "mme_cosine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_profile_reset": (C.c_int, [C.c_void_p]),
+    "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen libmme.so and type every export of include/mme.h (no GPU needed for this)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise MmeError(
+            f"{p} is missing: build it with `python -m multimodal_embeddings_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback for the embed/compare path."
+        )
+    lib = C.CDLL(p)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mme_abi_version() != 1:
+        raise MmeError(f"libmme ABI version {lib.mme_abi_version()} != 1")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Engine:
+    """One mme_ctx bound to one GPU.  Methods take torch CUDA tensors / numpy control arrays."""
+
+    def __init__(self, device: int = 0):
+        import torch
+
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise MmeError("no GPU visible to torch; the embed/compare path is HIP only (no CPU fallback)")
+        self.torch = torch
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self.lib.mme_create(self.device, C.byref(h))
+        if rc != 0:
+            raise MmeError(f"mme_create({device}) failed ({rc}): {self.lib.mme_last_error(None).decode()}")
+        self.h = h
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mme_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise MmeError(f"{what} failed ({rc}): {self.lib.mme_last_error(self.h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def load_vit(self, w: dict, eps: float = 1e-12):
+        def arr(name):
+            a = np.ascontiguousarray(w[name], dtype=np.float32)
+            self._keep.append(a)
+            return _fp(a)
+
+        layers = (_Layer * 12)()
+        for i in range(12):
+            p = f"layers.{i}."
+            L = layers[i]
+            L.ln1_g, L.ln1_b = arr(p + "layernorm_before.weight"), arr(p + "layernorm_before.bias")
+            L.q_w, L.q_b = arr(p + "attention.q_proj.weight"), arr(p + "attention.q_proj.bias")
+            L.k_w, L.k_b = arr(p + "attention.k_proj.weight"), arr(p + "attention.k_proj.bias")
+            L.v_w, L.v_b = arr(p + "attention.v_proj.weight"), arr(p + "attention.v_proj.bias")
+            L.o_w, L.o_b = arr(p + "attention.o_proj.weight"), arr(p + "attention.o_proj.bias")
+            L.ln2_g, L.ln2_b = arr(p + "layernorm_after.weight"), arr(p + "layernorm_after.bias")
+            L.fc1_w, L.fc1_b = arr(p + "mlp.fc1.weight"), arr(p + "mlp.fc1.bias")
+            L.fc2_w, L.fc2_b = arr(p + "mlp.fc2.weight"), arr(p + "mlp.fc2.bias")
+        W = _Weights(224, 16, 768, 12, 12, 3072, float(eps))
+        W.cls_token = arr("embeddings.cls_token")
+        W.pos_emb = arr("embeddings.position_embeddings")
+        W.patch_w = arr("embeddings.patch_embeddings.projection.weight")
+        W.patch_b = arr("embeddings.patch_embeddings.projection.bias")
+        W.lnf_g, W.lnf_b = arr("layernorm.weight"), arr("layernorm.bias")
+        W.layer = layers
+        self._check(self.lib.mme_load_vit(self.h, C.byref(W)), "mme_load_vit")
+        self._keep.clear()
+
+    def set_normalisation(self, mean, std):
+        m = (C.c_float * 3)(*mean)
+        s = (C.c_float * 3)(*std)
+        self._check(self.lib.mme_set_normalisation(self.h, m, s), "mme_set_normalisation")
+
+    def set_chunk(self, crops: int):
+        self._check(self.lib.mme_set_chunk(self.h, int(crops)), "mme_set_chunk")
+
+    # ---- hot path ----------------------------------------------------------------------------------
+    def _crop_tables(self, offs, hw):
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        hw = np.ascontiguousarray(hw, dtype=np.int32).reshape(-1, 2)
+        if len(offs) != len(hw):
+            raise ValueError("offs and hw disagree")
+        return offs, hw
+
+    def preprocess(self, pix, offs, hw):
+        """pix: uint8 CUDA tensor (concatenated HWC crops, >=16 spare bytes at the end)."""
+        t = self.torch
+        offs, hw = self._crop_tables(offs, hw)
+        n = len(offs)
+        patches = t.empty((n * 196, 768), dtype=t.bfloat16, device=pix.device)
+        self._check(self.lib.mme_preprocess(self.h, pix.data_ptr(), offs.ctypes.data, hw.ctypes.data, n, patches.data_ptr(), self._stream()), "mme_preprocess")
+        return patches
+
+    def vit_forward(self, patches, pool_token: int = 0, want_f32: bool = True, want_bf16: bool = True):
+        t = self.torch
+        n = patches.shape[0] // 196
+        e32 = t.empty((n, 768), dtype=t.float32, device=patches.device) if want_f32 else None
+        e16 = t.empty((n, 768), dtype=t.bfloat16, device=patches.device) if want_bf16 else None
+        self._check(self.lib.mme_vit_forward(self.h, patches.data_ptr(), n, int(pool_token), e32.data_ptr() if want_f32 else None,
+                                             e16.data_ptr() if want_bf16 else None, self._stream()), "mme_vit_forward")
+        return e32, e16
+
+    def embed(self, pix, offs, hw, pool_token: int = 0, out_f32=None, out_bf16=None, want_f32: bool = True, want_bf16: bool = True):
+        t = self.torch
+        offs, hw = self._crop_tables(offs, hw)
+        n = len(offs)
+        e32 = out_f32 if out_f32 is not None else (t.empty((n, 768), dtype=t.float32, device=pix.device) if want_f32 else None)
+        e16 = out_bf16 if out_bf16 is not None else (t.empty((n, 768), dtype=t.bfloat16, device=pix.device) if want_bf16 else None)
+        self._check(self.lib.mme_embed(self.h, pix.data_ptr(), offs.ctypes.data, hw.ctypes.data, n, int(pool_token),
+                                       e32.data_ptr() if e32 is not None else None, e16.data_ptr() if e16 is not None else None,
+                                       self._stream()), "mme_embed")
+        return e32, e16
+
+    def normalise_rows(self, x):
+        """f32 CUDA tensor [n,d] -> L2-normalised bf16 [n,d]."""
+        t = self.torch
+        x = x.contiguous()
+        y = t.empty(x.shape, dtype=t.bfloat16, device=x.device)
+        self._check(self.lib.mme_normalise_rows(self.h, x.data_ptr(), x.shape[0], x.shape[1], y.data_ptr(), self._stream()), "mme_normalise_rows")
+        return y
+
+    def cosine(self, a, b=None, out=None):
+        """a [m,d], b [n,d] bf16 CUDA tensors of L2-normalised rows -> f32 [m,n]."""
+        t = self.torch
+        b = a if b is None else b
+        m, d = a.shape
+        n = b.shape[0]
+        if out is None:
+            out = t.empty((m, n), dtype=t.float32, device=a.device)
+        assert a.dtype == t.bfloat16 and b.dtype == t.bfloat16 and a.is_contiguous() and b.is_contiguous()
+        self._check(self.lib.mme_cosine(self.h, a.data_ptr(), m, b.data_ptr(), n, d, out.data_ptr(), out.stride(0), self._stream()), "mme_cosine")
+        return out
+
+    def page_similarity(self, emb, area_pct, valid, page_offs, skip=None, *, max_query=10, top_k=10, max_dist=0.9, metric=0, normalise=True):
+        t = self.torch
+        N, d = emb.shape
+        page_offs = np.ascontiguousarray(page_offs, dtype=np.int32)
+        P = len(page_offs) - 1
+        S = t.empty((P, P), dtype=t.float64, device=emb.device)
+        self._check(self.lib.mme_page_similarity(self.h, emb.data_ptr(), N, d, area_pct.data_ptr(), valid.data_ptr(), page_offs.ctypes.data, P,
+                                                 skip.data_ptr() if skip is not None else None, int(max_query), int(top_k), float(max_dist),
+                                                 int(metric), int(bool(normalise)), S.data_ptr(), self._stream()), "mme_page_similarity")
+        return S
+
+    # ---- timing ------------------------------------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self.lib.mme_profile_enable(self.h, int(on)), "mme_profile_enable")
+        self._check(self.lib.mme_profile_reset(self.h), "mme_profile_reset")
+
+    def profile_read(self):
+        ms = (C.c_double * NUM_KERNEL_CLASSES)()
+        cnt = (C.c_int64 * NUM_KERNEL_CLASSES)()
+        self._check(self.lib.mme_profile_read_sync(self.h, ms, cnt), "mme_profile_read_sync")
+        return {KERNEL_CLASSES[i]: (ms[i], cnt[i]) for i in range(NUM_KERNEL_CLASSES)}

@@ -1,0 +1,590 @@
+// C ABI (include/mme.h): context, weight upload, workspace and the launch sequences.
+// No exceptions cross the boundary; every failure sets ctx->err and returns a code.
+#include "../../include/mme.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct LayerDev {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    bf16_t *qkv_w, *o_w, *fc1_w, *fc2_w;
+    float *qkv_b, *o_b, *fc1_b, *fc2_b;
+};
+
+enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6 };
+
+struct EventPair {
+    hipEvent_t a, b;
+    int cls;
+};
+
+}  // namespace
+
+struct mme_ctx {
+    int device = 0;
+    std::string err;
+    bool loaded = false;
+    float ln_eps = 1e-12f;
+    int chunk = 1024;
+    // weights
+    std::vector<void*> allocs;
+    float *cls = nullptr, *pos = nullptr, *patch_b = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+    bf16_t* patch_w = nullptr;
+    LayerDev layer[VIT_L];
+    float* lut = nullptr;  // [3,256]
+    // workspace (sized for `chunk` crops)
+    int ws_chunk = 0;
+    DevBuf x, hbuf, qkv, att, mlp, patches, tmp, crops, hwork, page_ws;
+    // host staging for crop tables
+    std::vector<CropDesc> h_crops;
+    std::vector<HWork> h_work;
+    // profiling
+    bool prof = false;
+    std::vector<EventPair> events;
+    size_t events_used = 0;
+};
+
+namespace {
+
+int fail(mme_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c)
+        c->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                            \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail((c), MME_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(mme_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return MME_OK;
+    if (b.p) {
+        HIP_TRY(c, hipDeviceSynchronize());
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) return fail(c, MME_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    b.bytes = bytes;
+    return MME_OK;
+}
+
+uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+int upload_f32(mme_ctx* c, const float* src, size_t n, float** dst) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, n * sizeof(float));
+    if (e != hipSuccess) return fail(c, MME_E_NOMEM, "hipMalloc weights: %s", hipGetErrorString(e));
+    c->allocs.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, src, n * sizeof(float), hipMemcpyHostToDevice));
+    *dst = (float*)p;
+    return MME_OK;
+}
+
+// concatenates up to three [rows_i, cols] f32 matrices row-wise, converts to bf16, uploads
+int upload_bf16(mme_ctx* c, const float* const* srcs, const size_t* rows, int nsrc, size_t cols, bf16_t** dst) {
+    size_t total = 0;
+    for (int i = 0; i < nsrc; ++i) total += rows[i] * cols;
+    std::vector<uint16_t> h(total);
+    size_t o = 0;
+    for (int i = 0; i < nsrc; ++i)
+        for (size_t k = 0; k < rows[i] * cols; ++k) h[o++] = f32_to_bf16_rne(srcs[i][k]);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, total * 2);
+    if (e != hipSuccess) return fail(c, MME_E_NOMEM, "hipMalloc weights: %s", hipGetErrorString(e));
+    c->allocs.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, h.data(), total * 2, hipMemcpyHostToDevice));
+    *dst = (bf16_t*)p;
+    return MME_OK;
+}
+
+int upload_f32_cat(mme_ctx* c, const float* const* srcs, const size_t* n, int nsrc, float** dst) {
+    std::vector<float> h;
+    for (int i = 0; i < nsrc; ++i) h.insert(h.end(), srcs[i], srcs[i] + n[i]);
+    return upload_f32(c, h.data(), h.size(), dst);
+}
+
+int ensure_workspace(mme_ctx* c) {
+    if (c->ws_chunk == c->chunk) return MME_OK;
+    const size_t rows = (size_t)c->chunk * VIT_T;
+    int r;
+    if ((r = ensure(c, c->x, rows * VIT_D * 2))) return r;
+    if ((r = ensure(c, c->hbuf, rows * VIT_D * 2))) return r;
+    if ((r = ensure(c, c->qkv, rows * 3 * VIT_D * 2))) return r;
+    if ((r = ensure(c, c->att, rows * VIT_D * 2))) return r;
+    if ((r = ensure(c, c->mlp, rows * VIT_F * 2))) return r;
+    c->ws_chunk = c->chunk;
+    return MME_OK;
+}
+
+struct Timed {
+    mme_ctx* c;
+    hipStream_t s;
+    EventPair* ev = nullptr;
+    Timed(mme_ctx* c_, hipStream_t s_, int cls) : c(c_), s(s_) {
+        if (!c->prof) return;
+        if (c->events_used == c->events.size()) {
+            EventPair p{};
+            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+            c->events.push_back(p);
+        }
+        ev = &c->events[c->events_used++];
+        ev->cls = cls;
+        (void)hipEventRecord(ev->a, s);
+    }
+    ~Timed() {
+        if (ev) (void)hipEventRecord(ev->b, s);
+    }
+};
+
+int set_lut(mme_ctx* c, const float mean[3], const float stdv[3]) {
+    // u8 -> ((f32)(f64(u) * (1/255)) - mean) / std : transformers image_transforms.py:89-125, :384-440
+    float h[768];
+    for (int ch = 0; ch < 3; ++ch)
+        for (int u = 0; u < 256; ++u) {
+            const float x = (float)((double)u * (1.0 / 255.0));
+            h[ch * 256 + u] = (x - mean[ch]) / stdv[ch];
+        }
+    if (!c->lut) {
+        void* p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, sizeof h));
+        c->lut = (float*)p;
+    }
+    HIP_TRY(c, hipMemcpy(c->lut, h, sizeof h, hipMemcpyHostToDevice));
+    return MME_OK;
+}
+
+int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, float* emb_f32, bf16_t* emb_bf16, hipStream_t s) {
+    const int M = n * VIT_T;
+    GemmArgs g{};
+    {
+        Timed t(c, s, KC_GEMM);
+        g.A = patches;
+        g.W = c->patch_w;
+        g.M = n * VIT_NP;
+        g.N = VIT_D;
+        g.K = VIT_D;
+        g.bias = c->patch_b;
+        g.pos = c->pos;
+        g.out = c->x.p;
+        g.ldo = VIT_D;
+        HIP_TRY(c, launch_gemm(EPI_PATCH, g, s));
+    }
+    {
+        Timed t(c, s, KC_LN);
+        HIP_TRY(c, launch_cls_rows(c->x.p, c->cls, c->pos, n, s));
+    }
+    for (int l = 0; l < VIT_L; ++l) {
+        const LayerDev& L = c->layer[l];
+        {
+            Timed t(c, s, KC_LN);
+            HIP_TRY(c, launch_layernorm(c->x.p, L.ln1_g, L.ln1_b, c->hbuf.p, M, c->ln_eps, s));
+        }
+        {
+            Timed t(c, s, KC_GEMM);
+            g = GemmArgs{};
+            g.A = c->hbuf.p; g.W = L.qkv_w; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
+            g.bias = L.qkv_b; g.out = c->qkv.p; g.ldo = 3 * VIT_D;
+            HIP_TRY(c, launch_gemm(EPI_BIAS, g, s));
+        }
+        {
+            Timed t(c, s, KC_ATTN);
+            HIP_TRY(c, launch_attention(c->qkv.p, c->att.p, n, s));
+        }
+        {
+            Timed t(c, s, KC_GEMM);
+            g = GemmArgs{};
+            g.A = c->att.p; g.W = L.o_w; g.M = M; g.N = VIT_D; g.K = VIT_D;
+            g.bias = L.o_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
+            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s));
+        }
+        {
+            Timed t(c, s, KC_LN);
+            HIP_TRY(c, launch_layernorm(c->x.p, L.ln2_g, L.ln2_b, c->hbuf.p, M, c->ln_eps, s));
+        }
+        {
+            Timed t(c, s, KC_GEMM);
+            g = GemmArgs{};
+            g.A = c->hbuf.p; g.W = L.fc1_w; g.M = M; g.N = VIT_F; g.K = VIT_D;
+            g.bias = L.fc1_b; g.out = c->mlp.p; g.ldo = VIT_F;
+            HIP_TRY(c, launch_gemm(EPI_BIAS_GELU, g, s));
+        }
+        {
+            Timed t(c, s, KC_GEMM);
+            g = GemmArgs{};
+            g.A = c->mlp.p; g.W = L.fc2_w; g.M = M; g.N = VIT_D; g.K = VIT_F;
+            g.bias = L.fc2_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
+            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s));
+        }
+    }
+    {
+        Timed t(c, s, KC_POOL);
+        HIP_TRY(c, launch_pool(c->x.p, c->lnf_g, c->lnf_b, n, pool_token, c->ln_eps, emb_f32, emb_bf16, s));
+    }
+    return MME_OK;
+}
+
+// Mllama single-tile fit (transformers image_processing_pil_mllama.py:246-295, canvas == tile)
+void fit_to_canvas(int h, int w, int* nh, int* nw) {
+    const double scale_h = (double)VIT_IMG / h, scale_w = (double)VIT_IMG / w;
+    if (scale_w < scale_h) {
+        *nw = VIT_IMG;
+        int v = (int)std::floor(h * scale_w);
+        if (v == 0) v = 1;
+        *nh = v < VIT_IMG ? v : VIT_IMG;
+    } else {
+        *nh = VIT_IMG;
+        int v = (int)std::floor(w * scale_h);
+        if (v == 0) v = 1;
+        *nw = v < VIT_IMG ? v : VIT_IMG;
+    }
+}
+
+int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const int32_t* hw, int n, bf16_t* patches, hipStream_t s) {
+    c->h_crops.resize(n);
+    c->h_work.clear();
+    size_t tmp_bytes = 0;
+    for (int i = 0; i < n; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h <= 0 || w <= 0 || h > 8000 || w > 8000)
+            return fail(c, MME_E_ARG, "crop %d has size %dx%d (h x w); supported 1..8000 (embedder.py:110-114 caps at 8000)", i, h, w);
+        CropDesc& d = c->h_crops[i];
+        d.src_off = offs[i];
+        d.h = h;
+        d.w = w;
+        fit_to_canvas(h, w, &d.new_h, &d.new_w);
+        d.tmp_off = 0;
+        if (d.new_w != w) {
+            d.tmp_off = (int64_t)tmp_bytes;
+            tmp_bytes += ((size_t)h * d.new_w * 3 + 15) & ~(size_t)15;
+            for (int r = 0; r < h; r += 16) c->h_work.push_back(HWork{i, r});
+        }
+    }
+    int r;
+    if ((r = ensure(c, c->crops, (size_t)n * sizeof(CropDesc)))) return r;
+    if ((r = ensure(c, c->tmp, tmp_bytes + 16))) return r;
+    if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
+    // pageable-host copies: the runtime stages them before returning, so the host vectors
+    // may be reused by the next chunk
+    HIP_TRY(c, hipMemcpyAsync(c->crops.p, c->h_crops.data(), (size_t)n * sizeof(CropDesc), hipMemcpyHostToDevice, s));
+    if (!c->h_work.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
+    Timed t(c, s, KC_PRE);
+    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(), s));
+    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, s));
+    return MME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mme_abi_version(void) { return MME_ABI_VERSION; }
+
+int mme_create(int device, mme_ctx** out) {
+    if (!out) return fail(nullptr, MME_E_ARG, "mme_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, MME_E_HIP, "mme_create: no HIP device visible (%s)", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= count) return fail(nullptr, MME_E_ARG, "mme_create: device %d out of range (0..%d)", device, count - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, MME_E_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, MME_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, MME_E_HIP, "mme_create: device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    mme_ctx* c = new (std::nothrow) mme_ctx();
+    if (!c) return fail(nullptr, MME_E_NOMEM, "mme_create: out of host memory");
+    c->device = device;
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    int r = set_lut(c, mean, stdv);
+    if (r) {
+        g_create_error = c->err;
+        delete c;
+        return r;
+    }
+    *out = c;
+    return MME_OK;
+}
+
+void mme_destroy(mme_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : c->allocs) (void)hipFree(p);
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->lut) (void)hipFree(c->lut);
+    for (auto& ev : c->events) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    delete c;
+}
+
+const char* mme_last_error(const mme_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int mme_load_vit(mme_ctx* c, const mme_vit_weights* w) {
+    if (!c || !w) return fail(c, MME_E_ARG, "mme_load_vit: null argument");
+    if (w->image_size != VIT_IMG || w->patch_size != VIT_PATCH || w->hidden != VIT_D || w->layers != VIT_L ||
+        w->heads != VIT_H || w->mlp != VIT_F)
+        return fail(c, MME_E_ARG, "mme_load_vit: only ViT-B/16 @224 geometry (224/16/768/12/12/3072) is built; got %d/%d/%d/%d/%d/%d",
+                    w->image_size, w->patch_size, w->hidden, w->layers, w->heads, w->mlp);
+    if (!w->cls_token || !w->pos_emb || !w->patch_w || !w->patch_b || !w->lnf_g || !w->lnf_b || !w->layer)
+        return fail(c, MME_E_ARG, "mme_load_vit: null tensor pointer");
+    if (c->loaded) return fail(c, MME_E_STATE, "mme_load_vit: weights already loaded; create a new context");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->ln_eps = w->ln_eps;
+    int r;
+    if ((r = upload_f32(c, w->cls_token, VIT_D, &c->cls))) return r;
+    if ((r = upload_f32(c, w->pos_emb, (size_t)VIT_T * VIT_D, &c->pos))) return r;
+    if ((r = upload_f32(c, w->patch_b, VIT_D, &c->patch_b))) return r;
+    if ((r = upload_f32(c, w->lnf_g, VIT_D, &c->lnf_g))) return r;
+    if ((r = upload_f32(c, w->lnf_b, VIT_D, &c->lnf_b))) return r;
+    {
+        const float* s[1] = {w->patch_w};
+        const size_t rows[1] = {VIT_D};
+        if ((r = upload_bf16(c, s, rows, 1, VIT_D, &c->patch_w))) return r;
+    }
+    for (int l = 0; l < VIT_L; ++l) {
+        const mme_vit_layer& a = w->layer[l];
+        const float* all[] = {a.ln1_g, a.ln1_b, a.q_w, a.q_b, a.k_w, a.k_b, a.v_w, a.v_b, a.o_w, a.o_b, a.ln2_g, a.ln2_b, a.fc1_w, a.fc1_b, a.fc2_w, a.fc2_b};
+        for (const float* p : all)
+            if (!p) return fail(c, MME_E_ARG, "mme_load_vit: layer %d has a null tensor pointer", l);
+        LayerDev& L = c->layer[l];
+        if ((r = upload_f32(c, a.ln1_g, VIT_D, &L.ln1_g))) return r;
+        if ((r = upload_f32(c, a.ln1_b, VIT_D, &L.ln1_b))) return r;
+        if ((r = upload_f32(c, a.ln2_g, VIT_D, &L.ln2_g))) return r;
+        if ((r = upload_f32(c, a.ln2_b, VIT_D, &L.ln2_b))) return r;
+        const float* qkv[3] = {a.q_w, a.k_w, a.v_w};
+        const size_t r3[3] = {VIT_D, VIT_D, VIT_D};
+        if ((r = upload_bf16(c, qkv, r3, 3, VIT_D, &L.qkv_w))) return r;
+        const float* qkvb[3] = {a.q_b, a.k_b, a.v_b};
+        if ((r = upload_f32_cat(c, qkvb, r3, 3, &L.qkv_b))) return r;
+        const float* o[1] = {a.o_w};
+        const size_t r1[1] = {VIT_D};
+        if ((r = upload_bf16(c, o, r1, 1, VIT_D, &L.o_w))) return r;
+        if ((r = upload_f32(c, a.o_b, VIT_D, &L.o_b))) return r;
+        const float* f1[1] = {a.fc1_w};
+        const size_t rf1[1] = {VIT_F};
+        if ((r = upload_bf16(c, f1, rf1, 1, VIT_D, &L.fc1_w))) return r;
+        if ((r = upload_f32(c, a.fc1_b, VIT_F, &L.fc1_b))) return r;
+        const float* f2[1] = {a.fc2_w};
+        if ((r = upload_bf16(c, f2, r1, 1, VIT_F, &L.fc2_w))) return r;
+        if ((r = upload_f32(c, a.fc2_b, VIT_D, &L.fc2_b))) return r;
+    }
+    c->loaded = true;
+    return MME_OK;
+}
+
+int mme_set_normalisation(mme_ctx* c, const float mean[3], const float stdv[3]) {
+    if (!c || !mean || !stdv) return fail(c, MME_E_ARG, "mme_set_normalisation: null argument");
+    for (int i = 0; i < 3; ++i)
+        if (!(stdv[i] > 0.f)) return fail(c, MME_E_ARG, "mme_set_normalisation: std[%d] must be > 0", i);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    return set_lut(c, mean, stdv);
+}
+
+int mme_set_chunk(mme_ctx* c, int crops) {
+    if (!c) return MME_E_ARG;
+    if (crops < 1 || crops > 16384) return fail(c, MME_E_ARG, "mme_set_chunk: %d outside 1..16384", crops);
+    c->chunk = crops;
+    return MME_OK;
+}
+
+int mme_preprocess(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const int32_t* hw, int n, uint16_t* patches, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (n < 0 || (n > 0 && (!pix || !offs || !hw || !patches))) return fail(c, MME_E_ARG, "mme_preprocess: null argument or n<0");
+    if (n == 0) return MME_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the crop tables of successive chunks reuse one device buffer: chunk so that stays ordered
+    for (int s0 = 0; s0 < n; s0 += c->chunk) {
+        const int m = n - s0 < c->chunk ? n - s0 : c->chunk;
+        if (s0 > 0) HIP_TRY(c, hipStreamSynchronize(s));
+        int r = preprocess_chunk(c, pix, offs + s0, hw + 2 * s0, m, (bf16_t*)patches + (size_t)s0 * VIT_NP * VIT_D, s);
+        if (r) return r;
+    }
+    return MME_OK;
+}
+
+int mme_vit_forward(mme_ctx* c, const uint16_t* patches, int n, int pool_token, float* emb_f32, uint16_t* emb_bf16, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (!c->loaded) return fail(c, MME_E_STATE, "mme_vit_forward: call mme_load_vit first");
+    if (n < 0 || (n > 0 && !patches)) return fail(c, MME_E_ARG, "mme_vit_forward: null patches or n<0");
+    if (pool_token < 0 || pool_token >= VIT_T) return fail(c, MME_E_ARG, "mme_vit_forward: pool_token %d outside 0..%d", pool_token, VIT_T - 1);
+    if (n == 0) return MME_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = ensure_workspace(c);
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    for (int s0 = 0; s0 < n; s0 += c->chunk) {
+        const int m = n - s0 < c->chunk ? n - s0 : c->chunk;
+        r = forward_chunk(c, (const bf16_t*)patches + (size_t)s0 * VIT_NP * VIT_D, m, pool_token,
+                          emb_f32 ? emb_f32 + (size_t)s0 * VIT_D : nullptr,
+                          emb_bf16 ? (bf16_t*)emb_bf16 + (size_t)s0 * VIT_D : nullptr, s);
+        if (r) return r;
+    }
+    return MME_OK;
+}
+
+int mme_embed(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const int32_t* hw, int n, int pool_token, float* emb_f32,
+              uint16_t* emb_bf16, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (!c->loaded) return fail(c, MME_E_STATE, "mme_embed: call mme_load_vit first");
+    if (n < 0 || (n > 0 && (!pix || !offs || !hw))) return fail(c, MME_E_ARG, "mme_embed: null argument or n<0");
+    if (pool_token < 0 || pool_token >= VIT_T) return fail(c, MME_E_ARG, "mme_embed: pool_token %d outside 0..%d", pool_token, VIT_T - 1);
+    if (n == 0) return MME_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = ensure_workspace(c);
+    if (r) return r;
+    if ((r = ensure(c, c->patches, (size_t)c->chunk * VIT_NP * VIT_D * 2))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    for (int s0 = 0; s0 < n; s0 += c->chunk) {
+        const int m = n - s0 < c->chunk ? n - s0 : c->chunk;
+        if (s0 > 0) HIP_TRY(c, hipStreamSynchronize(s));  // crop tables are reused per chunk
+        r = preprocess_chunk(c, pix, offs + s0, hw + 2 * s0, m, (bf16_t*)c->patches.p, s);
+        if (r) return r;
+        r = forward_chunk(c, (const bf16_t*)c->patches.p, m, pool_token, emb_f32 ? emb_f32 + (size_t)s0 * VIT_D : nullptr,
+                          emb_bf16 ? (bf16_t*)emb_bf16 + (size_t)s0 * VIT_D : nullptr, s);
+        if (r) return r;
+    }
+    return MME_OK;
+}
+
+int mme_normalise_rows(mme_ctx* c, const float* x, int64_t rows, int d, uint16_t* y, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (rows < 0 || d <= 0 || (d % 4) != 0) return fail(c, MME_E_ARG, "mme_normalise_rows: rows >= 0 and d %% 4 == 0 required");
+    if (rows == 0) return MME_OK;
+    if (!x || !y) return fail(c, MME_E_ARG, "mme_normalise_rows: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    Timed t(c, (hipStream_t)stream, KC_POOL);
+    HIP_TRY(c, launch_normalise_rows(x, rows, d, y, (hipStream_t)stream));
+    return MME_OK;
+}
+
+int mme_cosine(mme_ctx* c, const uint16_t* a, int m, const uint16_t* b, int n, int d, float* sim, int64_t ld, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (m < 0 || n < 0 || d <= 0 || (d % 64) != 0) return fail(c, MME_E_ARG, "mme_cosine: m,n >= 0 and d %% 64 == 0 required (d=%d)", d);
+    if (m == 0 || n == 0) return MME_OK;
+    if (!a || !b || !sim || ld < n) return fail(c, MME_E_ARG, "mme_cosine: null pointer or ld_sim < n");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    Timed t(c, s, KC_COS);
+    GemmArgs g{};
+    g.A = a; g.W = b; g.M = m; g.N = n; g.K = d; g.outf = sim; g.ldf = ld;
+    HIP_TRY(c, launch_gemm(EPI_F32, g, s));
+    return MME_OK;
+}
+
+int mme_page_similarity(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const double* area_pct, const uint8_t* valid,
+                        const int32_t* page_offs_host, int P, const uint8_t* skip, int max_query, int top_k, double max_dist,
+                        int metric, int normalise, double* S, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (P < 0 || N < 0 || d <= 0 || (d % 64) != 0) return fail(c, MME_E_ARG, "mme_page_similarity: bad sizes (P=%d N=%lld d=%d)", P, (long long)N, d);
+    if (P == 0) return MME_OK;
+    if (!S || !page_offs_host) return fail(c, MME_E_ARG, "mme_page_similarity: null pointer");
+    if (N > 0 && (!emb || !area_pct || !valid)) return fail(c, MME_E_ARG, "mme_page_similarity: null pointer");
+    if (max_query < 1 || top_k < 1 || max_query * top_k > 128) return fail(c, MME_E_ARG, "mme_page_similarity: max_query*top_k must be in 1..128");
+    if (metric != 0 && metric != 1) return fail(c, MME_E_ARG, "mme_page_similarity: metric must be 0 (cosine) or 1 (sqeuclidean)");
+    if (page_offs_host[0] != 0 || page_offs_host[P] != N) return fail(c, MME_E_ARG, "mme_page_similarity: page_offs must run 0..N");
+    for (int p = 0; p < P; ++p)
+        if (page_offs_host[p + 1] < page_offs_host[p]) return fail(c, MME_E_ARG, "mme_page_similarity: page_offs not monotone at %d", p);
+    if (N >= (int64_t)1 << 31) return fail(c, MME_E_ARG, "mme_page_similarity: N too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t slots = (size_t)P * max_query;
+    // workspace carve: page_offs | qrow | nvalid | maxbuf | qemb | qsim
+    size_t o_offs = 0;
+    size_t o_qrow = o_offs + (((size_t)(P + 1) * 4 + 255) & ~(size_t)255);
+    size_t o_nval = o_qrow + ((slots * 4 + 255) & ~(size_t)255);
+    size_t o_max = o_nval + (((size_t)P * 4 + 255) & ~(size_t)255);
+    size_t o_qemb = o_max + 256;
+    size_t o_qsim = o_qemb + ((slots * d * 2 + 255) & ~(size_t)255);
+    size_t total = o_qsim + slots * (size_t)(N > 0 ? N : 1) * 4;
+    int r = ensure(c, c->page_ws, total);
+    if (r) return r;
+    char* ws = (char*)c->page_ws.p;
+    HIP_TRY(c, hipMemcpyAsync(ws + o_offs, page_offs_host, (size_t)(P + 1) * 4, hipMemcpyHostToDevice, s));
+    Timed t(c, s, KC_PAGE);
+    PageSimArgs a{};
+    a.emb = emb; a.N = N; a.d = d; a.area_pct = area_pct; a.valid = valid;
+    a.page_offs = (const int32_t*)(ws + o_offs); a.P = P; a.skip = skip;
+    a.max_query = max_query; a.top_k = top_k; a.max_dist = max_dist; a.metric = metric; a.normalise = normalise;
+    a.S = S; a.qsim = (float*)(ws + o_qsim); a.qrow = (const int32_t*)(ws + o_qrow); a.qpage = (const int32_t*)(ws + o_nval);
+    a.qstart = nullptr; a.nq = (int)slots; a.qemb = ws + o_qemb; a.maxbuf = (double*)(ws + o_max);
+    HIP_TRY(c, launch_page_similarity(a, s));
+    return MME_OK;
+}
+
+int mme_profile_enable(mme_ctx* c, int on) {
+    if (!c) return MME_E_ARG;
+    c->prof = on != 0;
+    return MME_OK;
+}
+
+int mme_profile_reset(mme_ctx* c) {
+    if (!c) return MME_E_ARG;
+    c->events_used = 0;
+    return MME_OK;
+}
+
+int mme_profile_read_sync(mme_ctx* c, double ms[MME_NUM_KERNEL_CLASSES], int64_t launches[MME_NUM_KERNEL_CLASSES]) {
+    if (!c || !ms || !launches) return fail(c, MME_E_ARG, "mme_profile_read_sync: null argument");
+    for (int i = 0; i < MME_NUM_KERNEL_CLASSES; ++i) {
+        ms[i] = 0.0;
+        launches[i] = 0;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (size_t i = 0; i < c->events_used; ++i) {
+        EventPair& ev = c->events[i];
+        HIP_TRY(c, hipEventSynchronize(ev.b));
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, ev.a, ev.b));
+        ms[ev.cls] += t;
+        launches[ev.cls] += 1;
+    }
+    return MME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+// bf16 "TN" GEMM on MFMA for gfx950:  C[M,N] = A[M,K] . W[N,K]^T  with fused epilogues.
+//
+// Serves K2 (patch embed), K4 (QKV), K6 (o_proj + residual), K7 (fc1 + erf-GELU, fc2 +
+// residual) and K9 (all-pairs cosine, f32 out) of SURVEY.md §2a.  Both operands are
+// K-contiguous (Hugging Face Linear weights are [out, in]; embeddings are row vectors), so
+// an MFMA fragment is one 16-byte read on either side.
+//
+// Structure (128 x 128 x 64 tile, 4 waves as 2x2, each wave 64x64 = 4x4 MFMA 16x16x32):
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip.  The LDS image
+//     is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address
+//     and again on the ds_read (chunk ^= (row>>1)&7 within the 128-byte row).
+//   * double-buffered LDS (2 x 32 KiB), one barrier per K-tile; tile k+1 streams in while
+//     tile k feeds the matrix cores; 2 workgroups per CU cover each other's barriers.
+//   * operands are fed "swapped" (W fragment as MFMA A, activation fragment as MFMA B) so the
+//     accumulator holds 4 consecutive n per lane -> 8-byte bf16x4 / 16-byte f32x4 stores and
+//     bias / residual vector loads.
+//   * XCD-aware bijective tile order: consecutive tiles share the A row panel in one XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+// erf-GELU (transformers ACT2FN["gelu"]) with Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7),
+// branch-free; the result is rounded to bf16 (2^-9 relative) right after.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = __expf(-z * z);
+    const float erf_abs = 1.0f - p * t * e;
+    const float erf = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+    const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = id / tiles_n, tn = id - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const size_t ldb = (size_t)g.K * 2;
+    const char* Ag = (const char*)g.A;
+    const char* Wg = (const char*)g.W;
+
+    // Per-lane source offsets of the 4 LDS-DMA pieces this wave issues per operand tile.
+    // Piece i covers tile rows 8i..8i+7 (1 KiB); lane -> (row, 16-byte slot); the slot holds
+    // logical chunk slot ^ ((row>>1)&7).  Rows past the matrix edge re-read the last row.
+    size_t a_src[4], w_src[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int r = (wave * 4 + t) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int ra = min(m0 + r, g.M - 1), rw = min(n0 + r, g.N - 1);
+        a_src[t] = (size_t)ra * ldb + c * 16;
+        w_src[t] = (size_t)rw * ldb + c * 16;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* la = lds + buf * 2 * TILE_BYTES;
+        char* lw = la + TILE_BYTES;
+        const size_t koff = (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(Ag + a_src[t] + koff, la + (wave * 4 + t) * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(Wg + w_src[t] + koff, lw + (wave * 4 + t) * 1024);
+    };
+
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int fsw = (lane >> 1) & 7;  // (row>>1)&7 of this lane's fragment rows
+    int a_off[4], w_off[4];           // row byte offsets inside the tile
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_off[i] = (wr * 64 + i * 16 + fr) * (BK * 2);
+        w_off[i] = (wc * 64 + i * 16 + fr) * (BK * 2);
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* la = lds + cur * 2 * TILE_BYTES;
+        const char* lw = la + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ch = ((kk * 4 + fq) ^ fsw) << 4;
+            bf16x8 fa[4], fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *(const bf16x8*)(la + a_off[i] + ch);
+                fw[i] = *(const bf16x8*)(lw + w_off[i] + ch);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // Epilogue.  acc[i][j][r]: m = m0 + wr*64 + i*16 + (lane&15), n = n0 + wc*64 + j*16 + (lane>>4)*4 + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + fr;
+        if (m >= g.M) continue;
+        int64_t orow = m;
+        int prow = 0;
+        if (EPI == EPI_PATCH) {
+            const int b = m / VIT_NP;
+            prow = m - b * VIT_NP + 1;
+            orow = (int64_t)b * VIT_T + prow;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + fq * 4;
+            if (n >= g.N) continue;
+            f32x4 v = acc[i][j];
+            if (EPI == EPI_F32) {
+                float* o = g.outf + (int64_t)m * g.ldf + n;
+                if (n + 3 < g.N && ((g.ldf & 3) == 0)) {
+                    *(f32x4*)o = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < g.N) o[r] = v[r];
+                }
+                continue;
+            }
+            const f32x4 bv = *(const f32x4*)(g.bias + n);
+            v += bv;
+            if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (EPI == EPI_PATCH) {
+                v += *(const f32x4*)(g.pos + (int64_t)prow * g.N + n);
+            }
+            bf16_t* o = (bf16_t*)g.out + orow * g.ldo + n;
+            if (EPI == EPI_BIAS_RES) {
+                const bf16x4 rv = *(const bf16x4*)((const bf16_t*)g.res + orow * g.ldo + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+            bf16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
+            *(bf16x4*)o = ov;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
+    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    dim3 grid(tiles), block(256);
+    switch (epilogue) {
+        case EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS>, grid, block, 0, s, g); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS_GELU>, grid, block, 0, s, g); break;
+        case EPI_BIAS_RES: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS_RES>, grid, block, 0, s, g); break;
+        case EPI_PATCH: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_PATCH>, grid, block, 0, s, g); break;
+        case EPI_F32: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_F32>, grid, block, 0, s, g); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

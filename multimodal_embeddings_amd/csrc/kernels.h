@@ -1,0 +1,78 @@
+// Launcher declarations shared between the kernel translation units and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_bits;  // host-visible alias; device code uses __bf16
+
+enum GemmEpilogue {
+    EPI_BIAS = 0,       // out = bf16(acc + bias[n])                                  (QKV)
+    EPI_BIAS_GELU = 1,  // out = bf16(gelu_erf(acc + bias[n]))                        (fc1)
+    EPI_BIAS_RES = 2,   // out = bf16(acc + bias[n] + res[m,n])   (res may alias out) (o_proj, fc2)
+    EPI_PATCH = 3,      // row m=(b,p) -> out row b*197+1+p, + bias[n] + pos[1+p,n]   (patch embed)
+    EPI_F32 = 4         // outf[m,n] = acc                                            (cosine)
+};
+
+struct GemmArgs {
+    const void* A;   // bf16 [M, K] row-major
+    const void* W;   // bf16 [N, K] row-major ("TN": both operands K-contiguous)
+    int M, N, K;     // valid extents; K % 64 == 0
+    const float* bias;
+    void* out;       // bf16
+    int64_t ldo;
+    const void* res; // bf16, same layout as out
+    const float* pos;
+    float* outf;
+    int64_t ldf;
+};
+
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s);
+
+// LayerNorm over rows of 768 bf16 (f32 statistics), bf16 out.
+hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s);
+// x[b*197 + 0, :] = bf16(cls + pos[0])
+hipError_t launch_cls_rows(void* x, const float* cls, const float* pos, int B, hipStream_t s);
+// final LayerNorm on row b*197+tok, L2 normalise, write f32 and/or bf16
+hipError_t launch_pool(const void* x, const float* gamma, const float* beta, int B, int tok, float eps,
+                       float* emb_f32, void* emb_bf16, hipStream_t s);
+// f32 [rows,d] -> L2-normalised bf16 [rows,d]
+hipError_t launch_normalise_rows(const float* x, int64_t rows, int d, void* y, hipStream_t s);
+// fused multi-head attention, T=197, dh=64, 12 heads; qkv [B*197, 2304] -> out [B*197, 768]
+hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s);
+
+struct CropDesc {  // one per crop, built on the host by capi
+    int64_t src_off;   // byte offset into pix
+    int64_t tmp_off;   // byte offset into the horizontal-pass scratch (if used)
+    int32_t h, w;      // source size
+    int32_t new_h, new_w;
+};
+struct HWork {  // one block of the horizontal pass
+    int32_t crop, row0;
+};
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, hipStream_t s);
+hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
+                                    const float* lut /*[3,256]*/, void* patches, hipStream_t s);
+
+struct PageSimArgs {
+    const void* emb;        // bf16 [N, d]
+    int64_t N;
+    int d;
+    const double* area_pct; // [N]
+    const uint8_t* valid;   // [N]
+    const int32_t* page_offs; // device [P+1]
+    int P;
+    const uint8_t* skip;    // [P,P] or null
+    int max_query, top_k;
+    double max_dist;
+    int metric, normalise;
+    double* S;              // [P,P]
+    // workspace
+    float* qsim;            // [nq, N] f32
+    const int32_t* qrow;    // device [nq] row index of each query region
+    const int32_t* qpage;   // device [nq]
+    const int32_t* qstart;  // device [P+1] first query of each page
+    int nq;
+    void* qemb;             // bf16 [nq, d] gathered query rows
+    double* maxbuf;         // [1]
+};
+hipError_t launch_page_similarity(const PageSimArgs& a, hipStream_t s);

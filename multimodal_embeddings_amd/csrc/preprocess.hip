@@ -1,0 +1,192 @@
+// K1: batched variable-size crop -> Pillow-BILINEAR fit to 224 -> zero pad -> normalise ->
+// patchify (bf16 patch matrix [n*196, 768] in conv order (c, ky, kx)).
+//
+// Restates, bit for bit on the uint8 side, what every crop goes through in the reference
+// (deprecated_package/embedder.py:117-121 -> transformers image_processing_pil_mllama.py:
+// 483-541 -> Pillow libImaging/Resample.c, 8-bit path): separable triangle filter whose
+// support grows with the down-scale factor, 22-bit fixed-point coefficients, horizontal pass
+// then vertical pass with uint8 rounding after each, pad BEFORE normalisation.
+//
+// HBM-bound byte work (no MFMA): reads are 16-byte coalesced row streams staged through LDS,
+// the patch matrix is written as whole 1536-byte patch rows.
+//   resize_h          one workgroup per (crop, band of source rows): source row -> LDS,
+//                     fixed-point taps from an LDS coefficient table -> uint8 scratch row.
+//   resize_v_patchify one workgroup per (crop, patch row): vertical taps (or a plain copy
+//                     when the height is unchanged, e.g. the 224x224 synthetic crops) into a
+//                     16 x 224 x 3 uint8 LDS canvas, then LUT-normalise and emit 14 patches.
+//
+// Coefficients are computed on the device in f64 exactly as Resample.c does on the host;
+// contraction is disabled so no fused multiply-add changes a rounding.
+#include "common.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;
+constexpr int MAX_DIM = 8000;      // the reference caps crops at 8000 px (embedder.py:110-114)
+constexpr int MAX_TAPS = 160;      // window <= 2*ceil(scale)+1 and scale < 2*MAX_DIM/224
+constexpr int H_TABLE = 2 * MAX_DIM + 3 * VIT_IMG + 64;  // out * (2*ceil(in/out)+1) <= 2*in + 3*out
+constexpr int H_ROWS = 16;         // source rows per resize_h workgroup
+
+struct Taps {
+    int xmin, n;
+};
+
+// One output coordinate's window and fixed-point weights (Resample.c precompute_coeffs +
+// normalize_coeffs_8bpc, bilinear filter, box = whole image).
+__device__ __forceinline__ Taps compute_taps(int in_size, int out_size, int xx, int* kk /*[MAX_TAPS]*/) {
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    const double ss = 1.0 / filterscale;
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    const int n = xmax - xmin;
+    double ww = 0.0;
+    for (int x = 0; x < n; ++x) {
+        double t = (x + xmin - center + 0.5) * ss;
+        if (t < 0.0) t = -t;
+        const double w = t < 1.0 ? 1.0 - t : 0.0;
+        ww += w;
+    }
+    for (int x = 0; x < n; ++x) {
+        double t = (x + xmin - center + 0.5) * ss;
+        if (t < 0.0) t = -t;
+        double w = t < 1.0 ? 1.0 - t : 0.0;
+        if (ww != 0.0) w /= ww;
+        kk[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS));
+    }
+    return Taps{xmin, n};
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
+                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const HWork wk = work[blockIdx.x];
+    const CropDesc c = crops[wk.crop];
+    const int tid = threadIdx.x;
+    const int row_bytes = c.w * 3;
+    // LDS carve: [224] Taps, coefficient table with a per-crop stride, then one source row
+    Taps* taps = (Taps*)smem;
+    int* kk = (int*)(smem + VIT_IMG * sizeof(Taps));
+    uint8_t* rowbuf = (uint8_t*)(smem + VIT_IMG * sizeof(Taps) + H_TABLE * sizeof(int));
+    const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;  // >= 2*ceil(max(scale,1))+1
+    if (tid < c.new_w) taps[tid] = compute_taps(c.w, c.new_w, tid, kk + tid * kstride);
+    __syncthreads();
+    const uint8_t* src = pix + c.src_off;
+    uint8_t* dst = tmp + c.tmp_off;
+    const int rows = min(H_ROWS, c.h - wk.row0);
+    for (int yy = 0; yy < rows; ++yy) {
+        const int y = wk.row0 + yy;
+        const uint8_t* srow = src + (int64_t)y * row_bytes;
+        // the row start is only byte aligned: copy with 4-byte words from the aligned base
+        const uintptr_t a0 = (uintptr_t)srow & ~(uintptr_t)3;
+        const int lead = (int)((uintptr_t)srow - a0);
+        const int nwords = (lead + row_bytes + 3) >> 2;
+        for (int i = tid; i < nwords; i += 256) ((uint32_t*)rowbuf)[i] = ((const uint32_t*)a0)[i];
+        __syncthreads();
+        const uint8_t* rb = rowbuf + lead;
+        for (int e = tid; e < c.new_w * 3; e += 256) {
+            const int xx = e / 3, ch = e - xx * 3;
+            const Taps t = taps[xx];
+            const int* k = kk + xx * kstride;
+            int ss0 = 1 << (PRECISION_BITS - 1);
+            const uint8_t* p = rb + t.xmin * 3 + ch;
+            for (int x = 0; x < t.n; ++x) ss0 += (int)p[x * 3] * k[x];
+            dst[(int64_t)y * c.new_w * 3 + e] = clip8(ss0);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
+                                                         const CropDesc* __restrict__ crops, const float* __restrict__ lut,
+                                                         bf16_t* __restrict__ patches) {
+    __shared__ __attribute__((aligned(16))) uint8_t canvas[VIT_PATCH * VIT_IMG * 3 + 16];
+    __shared__ Taps taps[VIT_PATCH];
+    __shared__ int kk[VIT_PATCH * MAX_TAPS];
+    __shared__ float slut[3 * 256];
+    const int crop = blockIdx.x / VIT_GRID, py = blockIdx.x - crop * VIT_GRID;
+    const CropDesc c = crops[crop];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 768; i += 256) slut[i] = lut[i];
+    const bool hpass = c.new_w != c.w;       // Resample.c: horizontal pass only when width changes
+    const bool vpass = c.new_h != c.h;
+    const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
+    const int src_row_bytes = c.new_w * 3;   // after the horizontal pass (or unchanged width)
+    if (vpass && tid < VIT_PATCH) {
+        const int yy = py * VIT_PATCH + tid;
+        if (yy < c.new_h) taps[tid] = compute_taps(c.h, c.new_h, yy, kk + tid * MAX_TAPS);
+    }
+    __syncthreads();
+    // fill the 16-row canvas band: resized pixels, zero outside (pad precedes normalisation)
+    const uint8_t* band = src + (int64_t)py * VIT_PATCH * src_row_bytes;
+    if (!vpass && src_row_bytes == VIT_IMG * 3 && (py + 1) * VIT_PATCH <= c.new_h && (((uintptr_t)band) & 15) == 0) {
+        // unchanged 224-wide rows (the synthetic 224x224 workload): one contiguous 10752-byte band
+        for (int e = tid; e < VIT_PATCH * VIT_IMG * 3 / 16; e += 256) ((uint4*)canvas)[e] = ((const uint4*)band)[e];
+    } else
+    for (int e = tid; e < VIT_PATCH * VIT_IMG * 3; e += 256) {
+        const int ky = e / (VIT_IMG * 3), rem = e - ky * (VIT_IMG * 3);
+        const int yy = py * VIT_PATCH + ky;
+        uint8_t v = 0;
+        if (yy < c.new_h && rem < src_row_bytes) {
+            if (!vpass) {
+                v = src[(int64_t)yy * src_row_bytes + rem];
+            } else {
+                const Taps t = taps[ky];
+                const int* k = kk + ky * MAX_TAPS;
+                int ss0 = 1 << (PRECISION_BITS - 1);
+                const uint8_t* p = src + (int64_t)t.xmin * src_row_bytes + rem;
+                for (int y = 0; y < t.n; ++y) ss0 += (int)p[(int64_t)y * src_row_bytes] * k[y];
+                v = clip8(ss0);
+            }
+        }
+        canvas[e] = v;
+    }
+    __syncthreads();
+    // 14 patches x 768 values; a thread emits 8 consecutive kx of one (patch, c, ky)
+    bf16_t* out = patches + ((int64_t)crop * VIT_NP + py * VIT_GRID) * VIT_D;
+    for (int e = tid; e < VIT_GRID * VIT_D / 8; e += 256) {
+        const int px = e / (VIT_D / 8), q = e - px * (VIT_D / 8);
+        const int ch = q >> 5, ky = (q >> 1) & 15, kx0 = (q & 1) * 8;
+        const uint8_t* cp = canvas + ky * (VIT_IMG * 3) + (px * VIT_PATCH + kx0) * 3 + ch;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)slut[ch * 256 + cp[j * 3]];
+        *(bf16x8*)(out + (int64_t)px * VIT_D + q * 8) = o;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, hipStream_t s) {
+    if (nwork <= 0) return hipSuccess;
+    // Taps table + coefficient table + one source row of up to 8000 px (reference cap,
+    // embedder.py:110-114) with alignment slack
+    const size_t smem = VIT_IMG * sizeof(Taps) + H_TABLE * sizeof(int) + MAX_DIM * 3 + 32;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)resize_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work);
+    return hipGetLastError();
+}
+
+hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n, const float* lut,
+                                    void* patches, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(resize_v_patchify, dim3(n * VIT_GRID), dim3(256), 0, s, pix, tmp, crops, lut, (bf16_t*)patches);
+    return hipGetLastError();
+}

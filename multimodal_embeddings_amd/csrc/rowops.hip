@@ -1,0 +1,176 @@
+// Row-wise HBM-bound kernels of the ViT forward: LayerNorm (K3), [CLS] row initialisation,
+// and final-LayerNorm + pooling + L2 normalisation (K8).
+//
+// One 64-lane wave owns one 768-wide row: 3 x 8-byte (bf16x4) loads per lane, statistics
+// in f32 registers, two wave reductions (mean, then centred variance -- the same two-pass
+// form torch's LayerNorm uses, transformers modeling_vit.py:261-262,348), 8-byte stores.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void layernorm_rows(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                      int64_t rows, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * VIT_D;
+    float v[12];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const bf16x4 p = *(const bf16x4*)(xr + t * 256 + lane * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[t * 4 + j] = (float)p[j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += v[j];
+    const float mean = wave_sum(s) * (1.0f / VIT_D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        v[j] -= mean;
+        q += v[j] * v[j];
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / VIT_D) + eps);
+    bf16_t* yr = y + row * VIT_D;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int c = t * 256 + lane * 4;
+        const f32x4 gv = *(const f32x4*)(gamma + c);
+        const f32x4 bv = *(const f32x4*)(beta + c);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[t * 4 + j] * rstd * gv[j] + bv[j]);
+        *(bf16x4*)(yr + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void cls_rows(bf16_t* __restrict__ x, const float* __restrict__ cls,
+                                                const float* __restrict__ pos, int B) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    bf16_t* xr = x + (int64_t)b * VIT_T * VIT_D;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int c = t * 256 + lane * 4;
+        const f32x4 a = *(const f32x4*)(cls + c);
+        const f32x4 p = *(const f32x4*)(pos + c);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(a[j] + p[j]);
+        *(bf16x4*)(xr + c) = o;
+    }
+}
+
+// K8: restates last_pooling (deprecated_package/embedder.py:17-34) for one fixed token
+// index per sequence, after the final LayerNorm of that row only (the other 196 rows of
+// the last hidden state are never read by the reference's pooling).
+__global__ __launch_bounds__(256) void pool_ln_l2(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, int B, int tok, float eps,
+                                                  float* __restrict__ emb_f32, bf16_t* __restrict__ emb_bf16) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const bf16_t* xr = x + ((int64_t)b * VIT_T + tok) * VIT_D;
+    float v[12];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const bf16x4 p = *(const bf16x4*)(xr + t * 256 + lane * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[t * 4 + j] = (float)p[j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += v[j];
+    const float mean = wave_sum(s) * (1.0f / VIT_D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        v[j] -= mean;
+        q += v[j] * v[j];
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / VIT_D) + eps);
+    float n2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int c = t * 256 + lane * 4;
+        const f32x4 gv = *(const f32x4*)(gamma + c);
+        const f32x4 bv = *(const f32x4*)(beta + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[t * 4 + j] = v[t * 4 + j] * rstd * gv[j] + bv[j];
+            n2 += v[t * 4 + j] * v[t * 4 + j];
+        }
+    }
+    // torch.nn.functional.normalize: x / max(||x||_2, 1e-12)
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int c = t * 256 + lane * 4;
+        f32x4 o;
+        bf16x4 ob;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = v[t * 4 + j] * inv;
+            ob[j] = (bf16_t)o[j];
+        }
+        if (emb_f32) *(f32x4*)(emb_f32 + (int64_t)b * VIT_D + c) = o;
+        if (emb_bf16) *(bf16x4*)(emb_bf16 + (int64_t)b * VIT_D + c) = ob;
+    }
+}
+
+// f32 rows of any width d (d % 4 == 0) -> L2-normalised bf16 rows (one wave per row).  The
+// reference hands vectors around as Python float lists (embedder.py:132); this is the way
+// such vectors enter the bf16 cosine kernel, with the same normalisation as last_pooling.
+__global__ __launch_bounds__(256) void normalise_rows_f32(const float* __restrict__ x, int64_t rows, int d, bf16_t* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * d;
+    float n2 = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        n2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(n2)), 1e-12f);
+    bf16_t* yr = y + row * d;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *(const f32x4*)(xr + c);
+        bf16x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(v[j] * inv);
+        *(bf16x4*)(yr + c) = o;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_normalise_rows(const float* x, int64_t rows, int d, void* y, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(normalise_rows_f32, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, d, (bf16_t*)y);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(layernorm_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
+                       (bf16_t*)y, rows, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_cls_rows(void* x, const float* cls, const float* pos, int B, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cls_rows, dim3((B + 3) / 4), dim3(256), 0, s, (bf16_t*)x, cls, pos, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool(const void* x, const float* gamma, const float* beta, int B, int tok, float eps, float* emb_f32,
+                       void* emb_bf16, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pool_ln_l2, dim3((B + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, B, tok, eps, emb_f32,
+                       (bf16_t*)emb_bf16);
+    return hipGetLastError();
+}

@@ -1,0 +1,102 @@
+"""Multi-GPU sharding: one process per GPU, one RCCL all-gather of embedding shards.
+
+The reference's only parallelism is a replica per GPU inside one process with work
+interleaved `i % n_devices` over a thread pool, results returned through Python lists
+(deprecated_package/embedder.py:73-82,191-203,208-224); it has no collectives.  Here the
+corpus is partitioned into contiguous blocks (page groups stay intact, which K10's page
+segments rely on), each rank embeds its block, and the single exchange step of the
+path is an all-gather of the `[n_local, 768]` bf16 shards (12.6 MB per GPU at N=65536)
+so that every rank can compute its `[n_local, N]` row block of the cosine matrix.
+xGMI is point to point (7 links per GPU): one bulk all-gather per step, no chatty
+per-batch traffic.  backend "nccl" is RCCL on ROCm; the same code runs on gloo for the
+CPU tests.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block partition of n items: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_pages(page_offs, rank: int, world: int) -> tuple[int, int]:
+    """Partition whole pages so that region counts balance: returns a page range [p0, p1)."""
+    page_offs = np.asarray(page_offs)
+    P = len(page_offs) - 1
+    total = int(page_offs[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        cuts.append(int(np.searchsorted(page_offs, target, side="left")))
+    cuts.append(P)
+    cuts = np.maximum.accumulate(np.clip(cuts, 0, P))
+    return int(cuts[rank]), int(cuts[rank + 1])
+
+
+def init_from_env(backend: str | None = None):
+    """torch.distributed init from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def all_gather_rows(local, counts=None):
+    """Gather row blocks `[n_r, D]` from every rank into `[sum n_r, D]` on every rank.
+
+    Equal shards use one `all_gather_into_tensor`; ragged shards are padded to the largest
+    shard (counts = rows per rank, known from shard_range without communication).
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    n_local, d = local.shape
+    if counts is None:
+        counts = [n_local] * world
+    counts = [int(c) for c in counts]
+    assert counts[dist.get_rank()] == n_local, "counts disagree with the local shard"
+    mx = max(counts)
+    # gloo has no bf16 all_gather on every build: move 16-bit payloads as int16 views
+    payload = local.view(torch.int16) if local.dtype == torch.bfloat16 else local
+    if mx != n_local:
+        pad = torch.zeros((mx - n_local, d), dtype=payload.dtype, device=payload.device)
+        payload = torch.cat([payload, pad], dim=0)
+    payload = payload.contiguous()
+    out = torch.empty((world * mx, d), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(out, payload)
+    if any(c != mx for c in counts):
+        out = torch.cat([out[r * mx : r * mx + counts[r]] for r in range(world)], dim=0)
+    return out.view(torch.bfloat16) if local.dtype == torch.bfloat16 else out
+
+
+def all_reduce_max_float(value: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,198 @@
+"""Host mirror of deprecated_package/weighted_region_clustering.py:97-254 and :452-574.
+
+    S, names = compute_image_similarity_matrix(collection, image_paths)
+    result   = cluster_images(S, names)
+
+Same names, argument meaning and return shapes as the reference; the page-pair loop
+runs as kernel K10 (`mme_page_similarity`) over exact brute-force cosine instead of
+P^2*10 ChromaDB queries, and the agglomerative clustering runs as kernel K11
+(`mme_cluster_pages`).  Behaviours deliberately kept:
+  G5  `similarity_threshold` is accepted and ignored; the effective threshold is 0.1
+      (wrc:151) -- exposed as the real parameter `effective_threshold`;
+  G6  only the first 10 valid regions of the lower-index page query (wrc:199);
+  G3  `cluster_images` defaults to mode="reference_fallback" (euclidean over the rows
+      of D, what scikit-learn >= 1.4 executes through wrc:504-509, and what the bundled
+      golden labels pin); mode="precomputed" is the path the first `try:` intended;
+  G11 `cluster_images` mutates the caller's matrix diagonal in place (wrc:457).
+Behaviours deliberately NOT kept: the per-pair JSON progress file and its resume bug
+(G7, wrc:189-192): pairs are always recomputed.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from collections import defaultdict
+
+import numpy as np
+
+from . import config
+from .cross_compare import default_engine
+
+logger = logging.getLogger("multimodal_embeddings_amd")
+
+
+class RegionCollection:
+    """Minimal in-memory stand-in for the chroma collection (db_operations.py:17-63).
+
+    Holds what region_processor.py:141-149 upserts: ids, embeddings, metadatas (with
+    `parent_image_name`, `region_type`, `area_percentage`, `is_region`).  Only the calls
+    the compare stage makes are provided: `upsert`, `get`, `count`.
+    """
+
+    def __init__(self):
+        self.ids, self.embeddings, self.metadatas, self.documents = [], [], [], []
+        self._pos = {}
+
+    def upsert(self, ids, embeddings, documents=None, metadatas=None):
+        documents = documents or [None] * len(ids)
+        metadatas = metadatas or [None] * len(ids)
+        for i, e, d, m in zip(ids, embeddings, documents, metadatas):
+            if i in self._pos:
+                k = self._pos[i]
+                self.embeddings[k], self.documents[k], self.metadatas[k] = e, d, m
+            else:
+                self._pos[i] = len(self.ids)
+                self.ids.append(i)
+                self.embeddings.append(e)
+                self.documents.append(d)
+                self.metadatas.append(m)
+
+    add = upsert
+
+    def count(self):
+        return len(self.ids)
+
+    def get(self, ids=None, include=None, where=None):
+        rows = range(len(self.ids)) if ids is None else [self._pos[i] for i in ids if i in self._pos]
+        if where:
+            (key, cond), = where.items()
+            rows = [r for r in rows if self.metadatas[r] is not None and self.metadatas[r].get(key) == cond["$eq"]]
+        rows = list(rows)
+        return {
+            "ids": [self.ids[r] for r in rows],
+            "embeddings": [self.embeddings[r] for r in rows],
+            "metadatas": [self.metadatas[r] for r in rows],
+            "documents": [self.documents[r] for r in rows],
+        }
+
+
+def same_prefix_skip(image_names, prefix_length=config.PREFIX_LENGTH):
+    """uint8[P,P]: 1 where both names share their first `prefix_length` characters (wrc:179-186)."""
+    pre = np.array([n[: min(prefix_length, len(n))] for n in image_names], dtype=object)
+    return (pre[:, None] == pre[None, :]).astype(np.uint8)
+
+
+def build_page_table(all_entries, image_names):
+    """Group the collection's rows by parent page in `image_names` order (wrc:120-139).
+
+    Returns (emb float32 [N,D], area_percentage f64 [N], valid uint8 [N], page_offs int32 [P+1]);
+    row order inside a page is collection order, which the "first 10 regions" rule (G6)
+    and the tie order of equal distances depend on.
+    """
+    name_to_idx = {n: i for i, n in enumerate(image_names)}
+    per_page = defaultdict(list)
+    for r, meta in enumerate(all_entries["metadatas"]):
+        emb = all_entries["embeddings"][r]
+        if not meta or emb is None or len(emb) == 0:
+            continue
+        p = name_to_idx.get(meta.get("parent_image_name"))
+        if p is None:
+            continue
+        per_page[p].append(r)
+    rows, offs = [], [0]
+    for p in range(len(image_names)):
+        rows.extend(per_page.get(p, []))
+        offs.append(len(rows))
+    metas = [all_entries["metadatas"][r] for r in rows]
+    area = np.array([float(m.get("area_percentage", 0) or 0) for m in metas], dtype=np.float64)
+    ok_type = np.array([m.get("region_type") in config.REGION_TYPES_TO_PROCESS for m in metas], dtype=bool)
+    valid = ((area > 0) & ok_type).astype(np.uint8)
+    emb = np.asarray([all_entries["embeddings"][r] for r in rows], dtype=np.float32)
+    return emb, area, valid, np.asarray(offs, dtype=np.int32)
+
+
+def page_similarity_from_table(emb, area_percentage, valid, page_offs, image_names, *, metric="cosine",
+                               effective_threshold=config.EFFECTIVE_THRESHOLD, skip_same_prefix=True,
+                               prefix_length=config.PREFIX_LENGTH, max_query=config.PAGE_QUERY_REGIONS,
+                               top_k=config.PAGE_TOP_K, normalise=True, engine=None):
+    """Device entry: emb may be a bf16 CUDA tensor of unit rows (straight from the embedder)."""
+    from .cross_compare import to_unit_bf16
+
+    engine = engine or default_engine()
+    t = engine.torch
+    dev = t.device(f"cuda:{engine.device}")
+    e = to_unit_bf16(emb, engine)
+    a = t.from_numpy(np.ascontiguousarray(area_percentage, dtype=np.float64)).to(dev)
+    v = t.from_numpy(np.ascontiguousarray(valid, dtype=np.uint8)).to(dev)
+    skip = None
+    if skip_same_prefix:
+        skip = t.from_numpy(same_prefix_skip(image_names, prefix_length)).to(dev)
+    S = engine.page_similarity(e, a, v, page_offs, skip, max_query=max_query, top_k=top_k,
+                               max_dist=1.0 - effective_threshold, metric={"cosine": 0, "sqeuclidean": 1}[metric],
+                               normalise=normalise)
+    return S
+
+
+def compute_image_similarity_matrix(collection, image_paths, similarity_threshold=config.REGION_SIMILARITY_THRESHOLD,
+                                    skip_same_prefix=True, prefix_length=config.PREFIX_LENGTH, *, metric="cosine",
+                                    effective_threshold=config.EFFECTIVE_THRESHOLD, engine=None):
+    """wrc:97-254.  Returns (S float64 [P,P], image_names) or (None, None) without regions."""
+    image_names = [os.path.basename(p) for p in image_paths]
+    all_entries = collection.get(include=["metadatas", "embeddings"], where={"is_region": {"$eq": True}})
+    if not all_entries or len(all_entries["metadatas"]) == 0:
+        logger.warning("No regions found in the database. Make sure regions have been processed first.")
+        return None, None
+    emb, area, valid, offs = build_page_table(all_entries, image_names)
+    logger.info(f"Found {int(valid.sum())} regions across {len(image_names)} images")
+    logger.info(f"Using similarity threshold: {effective_threshold} (original: {similarity_threshold})")
+    if emb.shape[0] == 0:
+        S = np.zeros((len(image_names), len(image_names)))
+        np.fill_diagonal(S, 1.0)
+        return S, image_names
+    S = page_similarity_from_table(emb, area, valid, offs, image_names, metric=metric, effective_threshold=effective_threshold,
+                                   skip_same_prefix=skip_same_prefix, prefix_length=prefix_length, engine=engine)
+    return S.cpu().numpy(), image_names
+
+
+def cluster_images(similarity_matrix, image_names, n_clusters=None, *, mode="reference_fallback", engine=None):
+    """wrc:452-574.  Returns {n_clusters, clusters, cluster_cohesion, labels} or None."""
+    try:
+        if not isinstance(similarity_matrix, np.ndarray) or similarity_matrix.size == 0:
+            logger.error("Distance matrix is not a valid numpy array")
+            return None
+        if similarity_matrix.ndim != 2 or similarity_matrix.shape[0] != similarity_matrix.shape[1]:
+            logger.error("Distance matrix is not square")
+            return None
+        np.fill_diagonal(similarity_matrix, 1.0)  # wrc:457 (mutates the caller's array, G11)
+        if np.any(np.isnan(similarity_matrix)):
+            logger.error("Distance matrix contains NaN values")
+            return None
+        P = len(image_names)
+        if similarity_matrix.shape[0] != P:
+            raise ValueError("image_names and similarity_matrix disagree")
+        engine = engine or default_engine()
+        labels, k, scores = engine.cluster_pages(similarity_matrix, n_clusters, mode)
+        for kk, sc in scores:
+            logger.info(f"Testing {kk} clusters: silhouette score = {sc:.4f}")
+        clusters = defaultdict(list)
+        for i, lab in enumerate(labels):
+            clusters[int(lab)].append(image_names[i])
+        # intra-cluster cohesion (wrc:549-561): O(P^2) bookkeeping on the finished labels
+        cohesion = {}
+        for lab, imgs in clusters.items():
+            idx = [image_names.index(im) for im in imgs]
+            if len(idx) > 1:
+                sub = similarity_matrix[np.ix_(idx, idx)]
+                mask = ~np.eye(sub.shape[0], dtype=bool)
+                cohesion[lab] = float(np.mean(sub[mask])) if np.any(mask) else 0
+            else:
+                cohesion[lab] = 0.0
+        return {
+            "n_clusters": k,
+            "clusters": {str(kk): v for kk, v in clusters.items()},
+            "cluster_cohesion": cohesion,
+            "labels": [int(v) for v in labels],
+        }
+    except Exception as e:  # wrc:570-574
+        logger.error(f"Error during clustering: {str(e)}")
+        return None

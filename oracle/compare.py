@@ -78,8 +78,14 @@ def compute_image_similarity_matrix(
     max_query_regions: int = 10,
     top_k: int = 10,
     normalise: bool = True,
+    sim: np.ndarray | None = None,
 ):
     """weighted_region_clustering.py:97-254 restated over an in-memory region table.
+
+    `sim` (optional, [N,N]) supplies the cosine values instead of recomputing them from
+    `emb`: the parity tests pass the HIP cosine kernel's own f32 output here, so that the
+    top-k / threshold / reduction logic is compared decision for decision (a 1e-7
+    difference between an f32 and an f64 dot product can legitimately reorder a near-tie).
 
     emb[N,D], area_percentage[N] (0-100, region_processor.py:89-93), page_of[N]
     (index into `names`, rows in collection.get order), names[P] (page basenames
@@ -114,7 +120,11 @@ def compute_image_similarity_matrix(
             for r in ri[:max_query_regions]:  # :199
                 if area[r] == 0:
                     continue
-                d = distances(emb[r], emb[cand], metric)
+                if sim is None:
+                    d = distances(emb[r], emb[cand], metric)
+                else:
+                    c64 = np.asarray(sim[r, cand], dtype=np.float64)
+                    d = 1.0 - c64 if metric == "cosine" else 2.0 - 2.0 * c64
                 order = np.argsort(d, kind="stable")[:n_results]
                 for k in order:
                     dist = float(d[k])

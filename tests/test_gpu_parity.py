@@ -1,0 +1,269 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the oracle and the golden fixtures.
+
+Run on the MI355X box with `pytest -m gpu`.  Tolerances (BASELINE.json north_star):
+  * uint8 resize / patch matrix: bit-exact (the bf16 patch values are exact roundings of
+    the oracle's f32 pixel_values);
+  * embeddings: 1 - cos(gpu, oracle fp32) <= 1e-3 (bf16 MFMA path vs fp32 CPU oracle);
+    a stricter centred check guards against the trivial pass that near-identical
+    random-weight embeddings would allow;
+  * cosine matrix: |gpu - f64| <= 2e-6 (bf16 inputs are exact, f32 accumulate);
+  * page matrix: 1e-9 absolute on the normalised S given identical bf16 embeddings.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_embeddings_amd.weights import bf16_bits_to_f32, make_vit_weights, round_to_bf16, synthetic_crops  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def engine():
+    from multimodal_embeddings_amd._lib import Engine
+
+    e = Engine(0)
+    e.load_vit(make_vit_weights(seed=1))
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def engine_hot():
+    """Weights with 4x the init std: peaky softmax, large GELU arguments."""
+    from multimodal_embeddings_amd._lib import Engine
+
+    e = Engine(0)
+    e.load_vit(make_vit_weights(seed=1, std=0.08))
+    yield e
+    e.close()
+
+
+def _pack(arrays, device="cuda:0"):
+    hw = np.array([a.shape[:2] for a in arrays], dtype=np.int32).reshape(-1, 2)
+    sizes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+    offs = np.zeros(len(arrays), dtype=np.int64)
+    offs[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
+    buf = np.zeros(int(offs[-1] + sizes[-1]) + 16, dtype=np.uint8)
+    for a, o, s in zip(arrays, offs, sizes):
+        buf[o : o + s] = a.reshape(-1)
+    return torch.from_numpy(buf).to(device), offs, hw
+
+
+def _bf16_tensor_to_f32(t):
+    return t.float().cpu().numpy()
+
+
+def _golden_crops(golden_dir):
+    from PIL import Image
+
+    man = json.load(open(os.path.join(golden_dir, "crops_manifest.json")))
+    return [np.array(Image.open(os.path.join(golden_dir, "crops", c["file"])).convert("RGB")) for c in man["crops"]], man
+
+
+def test_preprocess_bit_exact_real_crops(engine, golden_dir):
+    from oracle import preprocess as opre
+
+    arrays, man = _golden_crops(golden_dir)
+    pix, offs, hw = _pack(arrays)
+    patches = engine.preprocess(pix, offs, hw)
+    torch.cuda.synchronize()
+    got = _bf16_tensor_to_f32(patches).reshape(len(arrays), 196, 768)
+    for i, a in enumerate(arrays):
+        want = round_to_bf16(opre.preprocess_to_patches(a))
+        assert np.array_equal(got[i], want), man["crops"][i]["file"]
+
+
+def test_preprocess_bit_exact_synthetic_shapes(engine):
+    from oracle import preprocess as opre
+
+    rng = np.random.default_rng(11)
+    shapes = [(224, 224), (20, 63), (63, 20), (1, 1), (1, 300), (300, 1), (5114, 60), (37, 3862), (223, 225), (225, 223),
+              (448, 448), (100, 100), (1000, 333), (224, 100), (100, 224), (17, 8000), (8000, 9), (2000, 1999), (16, 16), (500, 224)]
+    arrays = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+    pix, offs, hw = _pack(arrays)
+    patches = engine.preprocess(pix, offs, hw)
+    torch.cuda.synchronize()
+    got = _bf16_tensor_to_f32(patches).reshape(len(arrays), 196, 768)
+    for i, a in enumerate(arrays):
+        want = round_to_bf16(opre.preprocess_to_patches(a))
+        assert np.array_equal(got[i], want), shapes[i]
+
+
+def test_preprocess_rejects_oversize(engine):
+    from multimodal_embeddings_amd._lib import MmeError
+
+    pix = torch.zeros(64, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(MmeError):
+        engine.preprocess(pix, np.array([0]), np.array([[8001, 1]]))
+    with pytest.raises(MmeError):
+        engine.preprocess(pix, np.array([0]), np.array([[0, 5]]))
+
+
+def _oracle_embed(arrays, w, pool):
+    from oracle import preprocess as opre
+    from oracle import vit as ovit
+
+    patches = np.stack([opre.preprocess_to_patches(a) for a in arrays])
+    return ovit.vit_embed(patches, w, pool=pool)
+
+
+def _check_embeddings(got, want, tol=1e-3):
+    got = got / np.linalg.norm(got, axis=1, keepdims=True)
+    cos = np.sum(got * want, axis=1)
+    assert np.all(1.0 - cos <= tol), (1.0 - cos).max()
+    # centred check: remove the common component so near-identical embeddings cannot pass trivially
+    if len(got) >= 4:
+        mu = want.mean(axis=0, keepdims=True)
+        g, w_ = got - mu, want - mu
+        ccos = np.sum(g * w_, axis=1) / (np.linalg.norm(g, axis=1) * np.linalg.norm(w_, axis=1))
+        assert np.all(ccos > 0.98), ccos.min()
+    return float((1.0 - cos).max())
+
+
+@pytest.mark.parametrize("pool,token", [("cls", 0), ("last", 196)])
+def test_embed_real_crops_within_1e3_cosine(engine, golden_dir, pool, token):
+    arrays, _ = _golden_crops(golden_dir)
+    pix, offs, hw = _pack(arrays)
+    e32, e16 = engine.embed(pix, offs, hw, pool_token=token)
+    torch.cuda.synchronize()
+    want = _oracle_embed(arrays, make_vit_weights(seed=1), pool)
+    _check_embeddings(e32.cpu().numpy(), want)
+    # bf16 copy is the rounding of the f32 copy, and rows are unit length
+    assert np.array_equal(_bf16_tensor_to_f32(e16), round_to_bf16(e32.cpu().numpy()))
+    assert np.allclose(np.linalg.norm(e32.cpu().numpy(), axis=1), 1.0, atol=1e-5)
+
+
+def test_embed_hot_weights(engine_hot, golden_dir):
+    arrays, _ = _golden_crops(golden_dir)
+    arrays = arrays[:12]
+    pix, offs, hw = _pack(arrays)
+    e32, _ = engine_hot.embed(pix, offs, hw)
+    torch.cuda.synchronize()
+    want = _oracle_embed(arrays, make_vit_weights(seed=1, std=0.08), "cls")
+    _check_embeddings(e32.cpu().numpy(), want)
+
+
+def test_embed_matches_transformers_golden(engine, golden_dir):
+    """vit_cases.npz was produced by transformers.ViTModel itself (make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "vit_cases.npz"))
+    crops = synthetic_crops(int(g["n"]), seed=int(g["crop_seed"]))
+    pix, offs, hw = _pack(list(crops))
+    for pool, token in (("cls", 0), ("last", 196)):
+        e32, _ = engine.embed(pix, offs, hw, pool_token=token)
+        torch.cuda.synchronize()
+        cos = np.sum(e32.cpu().numpy() * g[f"std002_{pool}"], axis=1)
+        assert np.all(1.0 - cos <= 1e-3), (pool, 1.0 - cos)
+
+
+def test_embed_chunking_and_ragged_batch(engine):
+    """Results must not depend on the chunk size or on the position inside a batch."""
+    crops = synthetic_crops(37, seed=3)
+    pix, offs, hw = _pack(list(crops))
+    engine.set_chunk(1024)
+    a, _ = engine.embed(pix, offs, hw)
+    engine.set_chunk(8)
+    b, _ = engine.embed(pix, offs, hw)
+    engine.set_chunk(1024)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    c, _ = engine.embed(pix, offs[5:6], hw[5:6])
+    assert torch.equal(a[5:6], c)
+    e0, _ = engine.embed(pix, offs[:0], hw[:0])
+    assert e0.shape == (0, 768)
+
+
+def test_cosine_matches_f64(engine):
+    rng = np.random.default_rng(2)
+    for m, n, d in [(1, 1, 64), (5, 300, 768), (257, 129, 768), (1000, 1000, 128), (130, 4100, 768)]:
+        a = rng.standard_normal((m, d)).astype(np.float32)
+        b = rng.standard_normal((n, d)).astype(np.float32)
+        ta = engine.normalise_rows(torch.from_numpy(a).cuda())
+        tb = engine.normalise_rows(torch.from_numpy(b).cuda())
+        sim = engine.cosine(ta, tb)
+        torch.cuda.synchronize()
+        fa, fb = ta.float().cpu().numpy().astype(np.float64), tb.float().cpu().numpy().astype(np.float64)
+        want = fa @ fb.T
+        assert np.abs(sim.cpu().numpy() - want).max() <= 2e-6, (m, n, d)
+        # normalise_rows itself: unit rows, rounding of the f32 normalisation
+        ref = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
+        assert np.abs(fa - ref).max() <= 2.0 ** -8
+
+
+def test_cross_compare_api(engine):
+    from multimodal_embeddings_amd.cross_compare import cross_compare
+
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal((50, 768)).astype(np.float32) * 3.0
+    sim = cross_compare(v.tolist(), engine=engine)
+    assert isinstance(sim, np.ndarray) and sim.shape == (50, 50)
+    from oracle.compare import cosine_matrix
+
+    assert np.abs(sim - cosine_matrix(v)).max() < 1.5e-2  # bf16 rounding of the inputs
+    assert np.allclose(np.diag(sim), 1.0, atol=1e-2)
+    with pytest.raises(ValueError):
+        cross_compare([[1.0] * 64, None], engine=engine)
+
+
+def _pagesim_inputs(g, prefix):
+    emb = g[f"{prefix}_emb"]
+    d = emb.shape[1]
+    pad = (-d) % 64
+    if pad:
+        emb = np.concatenate([emb, np.zeros((emb.shape[0], pad), dtype=emb.dtype)], axis=1)
+    return emb, g[f"{prefix}_area_percentage"], g[f"{prefix}_page_of"]
+
+
+@pytest.mark.parametrize("metric", ["cosine", "sqeuclidean"])
+def test_page_similarity_vs_oracle_and_reference_golden(engine, golden_dir, metric):
+    from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+    from oracle import compare as ocmp
+
+    g = np.load(os.path.join(golden_dir, "pagesim_cases.npz"))
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    names = [p["name"] for p in pages]
+    emb, area, page_of = _pagesim_inputs(g, "real")
+    assert np.all(np.diff(page_of) >= 0)
+    offs = np.searchsorted(page_of, np.arange(len(names) + 1)).astype(np.int32)
+    e16 = engine.normalise_rows(torch.from_numpy(emb.astype(np.float32)).cuda())
+    S = page_similarity_from_table(e16, area, (area > 0).astype(np.uint8), offs, names, metric=metric, engine=engine)
+    torch.cuda.synchronize()
+    S = S.cpu().numpy()
+    # oracle on the kernel's own cosine values: every top-k / threshold / sum decision must agree
+    sims = engine.cosine(e16, e16).cpu().numpy()
+    want, _ = ocmp.compute_image_similarity_matrix(None, area, page_of, names, metric=metric, sim=sims)
+    assert np.abs(S - want).max() <= 1e-12
+    # oracle recomputing cosine in f64 from the same bf16 vectors (near-ties may reorder)
+    want64, _ = ocmp.compute_image_similarity_matrix(e16.float().cpu().numpy(), area, page_of, names, metric=metric)
+    assert np.abs(S - want64).max() <= 5e-3
+    # and the reference's own output on the unrounded vectors (bf16 rounding of inputs only)
+    assert np.abs(S - g[f"real_S_{metric}"]).max() <= 2e-2
+    assert np.array_equal(S == 0, want == 0)
+    assert np.array_equal(np.diag(S), np.ones(len(names)))
+
+
+def test_page_similarity_edge_cases(engine, golden_dir):
+    from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+    from oracle import compare as ocmp
+
+    g = np.load(os.path.join(golden_dir, "pagesim_cases.npz"))
+    names = json.load(open(os.path.join(golden_dir, "pagesim_names.json")))["names"]
+    emb, area, page_of = _pagesim_inputs(g, "syn")
+    types_ok = g["syn_types_ok"]
+    offs = np.searchsorted(page_of, np.arange(len(names) + 1)).astype(np.int32)
+    e16 = engine.normalise_rows(torch.from_numpy(emb.astype(np.float32)).cuda())
+    valid = ((area > 0) & types_ok).astype(np.uint8)
+    types = ["plain_text" if ok else "abandon" for ok in types_ok]
+    sims = engine.cosine(e16, e16).cpu().numpy()
+    for metric in ("cosine", "sqeuclidean"):
+        S = page_similarity_from_table(e16, area, valid, offs, names, metric=metric, engine=engine).cpu().numpy()
+        want, _ = ocmp.compute_image_similarity_matrix(None, area, page_of, names, types, metric=metric, sim=sims)
+        assert np.abs(S - want).max() <= 1e-12, metric
+        assert S[2, 3] == 0 and S[4].sum() == 1.0
+    S = page_similarity_from_table(e16, area, valid, offs, names, skip_same_prefix=False, normalise=False, engine=engine).cpu().numpy()
+    want, _ = ocmp.compute_image_similarity_matrix(None, area, page_of, names, types, skip_same_prefix=False, normalise=False, sim=sims)
+    assert np.abs(S - want).max() <= 1e-15
+    assert S[2, 3] > 0
