@@ -144,8 +144,24 @@ int mme_page_similarity(mme_ctx* ctx, const uint16_t* emb_dev, int64_t N, int d,
                         int max_query, int top_k, double max_dist, int metric, int normalise, double* S_dev,
                         void* stream);
 
+/* ---- K11: page clustering -------------------------------------------------------------------
+ * Replaces cluster_images' arithmetic (weighted_region_clustering.py:476-543): average
+ * linkage + silhouette-chosen k.  S_dev double[P,P] page similarities with unit diagonal
+ * (2 <= P <= 4096).
+ *   n_clusters  0 = choose k in 2..min(10,P) (or ..min(3,P) when fewer than 10 entries of S
+ *               exceed 0.01 off the diagonal, wrc:482-490) by silhouette, strict-> argmax
+ *               from -1 (wrc:492,517); >0 = cut at that k (wrc:531-543)
+ *   mode        0 = what scikit-learn >= 1.4 executes through the reference's TypeError
+ *               fallback (wrc:504-509): euclidean metric over the ROWS of D = 1-S -- the
+ *               path the bundled golden labels pin; 1 = D as a precomputed distance matrix
+ *   labels_dev  int32[P]  sklearn label numbering (_hc_cut heap order)
+ *   k_dev       int32[1]  chosen number of clusters
+ *   scores_dev  double[16]: scores[k] = silhouette at k (NaN where not evaluated) */
+int mme_cluster_pages(mme_ctx* ctx, const double* S_dev, int P, int n_clusters, int mode, int32_t* labels_dev,
+                      int32_t* k_dev, double* scores_dev, void* stream);
+
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
- * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce */
+ * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster */
 #define MME_NUM_KERNEL_CLASSES 8
 int mme_profile_enable(mme_ctx* ctx, int on);
 int mme_profile_reset(mme_ctx* ctx);

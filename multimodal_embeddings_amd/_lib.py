@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmme.so")
 
 NUM_KERNEL_CLASSES = 8
-KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "reserved")
+KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "cluster")
 
 
 class MmeError(RuntimeError):
@@ -54,6 +54,7 @@ EXPORTS = {
     "mme_cosine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mme_cluster_pages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
     "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -68,6 +69,11 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # torch ships its own libamdhip64; libmme.so must bind to THAT runtime (one HIP runtime per
+    # process), so torch is always loaded first.  Loading libmme.so first makes the second
+    # runtime report "no ROCm-capable device".
+    import torch  # noqa: F401
+
     if not os.path.exists(p):
         raise MmeError(
             f"{p} is missing: build it with `python -m multimodal_embeddings_amd.build` "
@@ -229,6 +235,24 @@ class Engine:
                                                  skip.data_ptr() if skip is not None else None, int(max_query), int(top_k), float(max_dist),
                                                  int(metric), int(bool(normalise)), S.data_ptr(), self._stream()), "mme_page_similarity")
         return S
+
+    def cluster_pages(self, S, n_clusters=None, mode="reference_fallback"):
+        """S: numpy f64 [P,P] (unit diagonal) or CUDA f64 tensor -> (labels int list, k, [(k, silhouette)...])."""
+        t = self.torch
+        dev = t.device(f"cuda:{self.device}")
+        Sd = S if isinstance(S, t.Tensor) else t.from_numpy(np.ascontiguousarray(S, dtype=np.float64)).to(dev)
+        Sd = Sd.contiguous()
+        P = Sd.shape[0]
+        if P < 2:
+            raise MmeError("cluster_pages needs at least 2 pages")
+        labels = t.empty(P, dtype=t.int32, device=dev)
+        k = t.empty(1, dtype=t.int32, device=dev)
+        scores = t.empty(16, dtype=t.float64, device=dev)
+        m = {"reference_fallback": 0, "precomputed": 1}[mode]
+        self._check(self.lib.mme_cluster_pages(self.h, Sd.data_ptr(), P, int(n_clusters or 0), m, labels.data_ptr(), k.data_ptr(),
+                                               scores.data_ptr(), self._stream()), "mme_cluster_pages")
+        sc = scores.cpu().numpy()
+        return labels.cpu().numpy().tolist(), int(k.item()), [(i, float(sc[i])) for i in range(2, 16) if sc[i] == sc[i]]
 
     # ---- timing ------------------------------------------------------------------------------------
     def profile(self, on: bool):

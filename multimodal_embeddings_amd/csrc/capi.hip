@@ -29,7 +29,7 @@ struct LayerDev {
     float *qkv_b, *o_b, *fc1_b, *fc2_b;
 };
 
-enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6 };
+enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7 };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -52,7 +52,7 @@ struct mme_ctx {
     float* lut = nullptr;  // [3,256]
     // workspace (sized for `chunk` crops)
     int ws_chunk = 0;
-    DevBuf x, hbuf, qkv, att, mlp, patches, tmp, crops, hwork, page_ws;
+    DevBuf x, hbuf, qkv, att, mlp, patches, tmp, crops, hwork, page_ws, cluster_ws;
     // host staging for crop tables
     std::vector<CropDesc> h_crops;
     std::vector<HWork> h_work;
@@ -350,7 +350,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -554,6 +554,23 @@ int mme_page_similarity(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const
     a.S = S; a.qsim = (float*)(ws + o_qsim); a.qrow = (const int32_t*)(ws + o_qrow); a.qpage = (const int32_t*)(ws + o_nval);
     a.qstart = nullptr; a.nq = (int)slots; a.qemb = ws + o_qemb; a.maxbuf = (double*)(ws + o_max);
     HIP_TRY(c, launch_page_similarity(a, s));
+    return MME_OK;
+}
+
+int mme_cluster_pages(mme_ctx* c, const double* S, int P, int n_clusters, int mode, int32_t* labels, int32_t* k_out, double* scores,
+                      void* stream) {
+    if (!c) return MME_E_ARG;
+    if (!S || !labels || !k_out || !scores) return fail(c, MME_E_ARG, "mme_cluster_pages: null pointer");
+    if (P < 2 || P > 4096) return fail(c, MME_E_ARG, "mme_cluster_pages: P=%d outside 2..4096", P);
+    if (n_clusters < 0 || n_clusters > P) return fail(c, MME_E_ARG, "mme_cluster_pages: n_clusters=%d outside 0..P", n_clusters);
+    if (mode != 0 && mode != 1) return fail(c, MME_E_ARG, "mme_cluster_pages: mode must be 0 (reference fallback) or 1 (precomputed)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = ensure(c, c->cluster_ws, cluster_workspace_bytes(P));
+    if (r) return r;
+    hipStream_t s = (hipStream_t)stream;
+    Timed t(c, s, KC_CLUSTER);
+    HIP_TRY(c, hipMemsetAsync(scores, 0xff, 16 * sizeof(double), s));  // NaN = "not evaluated"
+    HIP_TRY(c, launch_cluster(S, P, n_clusters, mode, (char*)c->cluster_ws.p, labels, k_out, scores, s));
     return MME_OK;
 }
 

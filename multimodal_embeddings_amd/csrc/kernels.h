@@ -76,3 +76,8 @@ struct PageSimArgs {
     double* maxbuf;         // [1]
 };
 hipError_t launch_page_similarity(const PageSimArgs& a, hipStream_t s);
+
+// K11 page clustering (cluster.hip): labels_out int32[P], k_out int32[1], scores_out double[16]
+hipError_t launch_cluster(const double* S, int P, int n_clusters, int mode, char* ws, int32_t* labels_out, int32_t* k_out,
+                          double* scores_out, hipStream_t s);
+size_t cluster_workspace_bytes(int P);

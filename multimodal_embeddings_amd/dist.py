@@ -78,8 +78,9 @@ def all_gather_rows(local, counts=None):
     counts = [int(c) for c in counts]
     assert counts[dist.get_rank()] == n_local, "counts disagree with the local shard"
     mx = max(counts)
-    # gloo has no bf16 all_gather on every build: move 16-bit payloads as int16 views
-    payload = local.view(torch.int16) if local.dtype == torch.bfloat16 else local
+    # gloo implements neither bf16 nor int16 all_gather: 16-bit payloads travel as bytes
+    payload = local.contiguous().view(torch.uint8) if local.dtype == torch.bfloat16 else local
+    d = payload.shape[1]
     if mx != n_local:
         pad = torch.zeros((mx - n_local, d), dtype=payload.dtype, device=payload.device)
         payload = torch.cat([payload, pad], dim=0)
