@@ -43,7 +43,9 @@ def cpu_baseline(sample_crops: np.ndarray, weights, budget_s: float = 20.0):
     from oracle import preprocess as opre
     from oracle import vit as ovit
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one job a 16-CPU share per GPU whatever os.cpu_count() says; more
+    # threads than that only oversubscribe
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     embs = []
     t0 = time.perf_counter()
     done = 0

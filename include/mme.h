@@ -84,6 +84,11 @@ int mme_set_normalisation(mme_ctx* ctx, const float mean[3], const float std[3])
 /* Rows of the internal activation workspace = crops per encoder pass (default 1024). */
 int mme_set_chunk(mme_ctx* ctx, int crops_per_pass);
 
+/* Tuning / test knob: which MFMA GEMM tiling serves K2/K4/K6/K7/K9.  0 = by shape (default),
+ * 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel.  Results are bit-identical across variants
+ * (same MFMA instruction, same K order per output element). */
+int mme_set_gemm_variant(mme_ctx* ctx, int variant);
+
 /* ---- K1: crop -> resize -> pad -> normalise -> patchify ------------------------------
  * Replaces, per crop, `processor(images=[image])` (embedder.py:117-121; transformers
  * image_processing_pil_mllama.py:483-541 with tile 224, one tile): aspect-preserving

@@ -47,6 +47,7 @@ EXPORTS = {
     "mme_load_vit": (C.c_int, [C.c_void_p, C.POINTER(_Weights)]),
     "mme_set_normalisation": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mme_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -164,6 +165,9 @@ class Engine:
         m = (C.c_float * 3)(*mean)
         s = (C.c_float * 3)(*std)
         self._check(self.lib.mme_set_normalisation(self.h, m, s), "mme_set_normalisation")
+
+    def set_gemm_variant(self, variant: int):
+        self._check(self.lib.mme_set_gemm_variant(self.h, int(variant)), "mme_set_gemm_variant")
 
     def set_chunk(self, crops: int):
         self._check(self.lib.mme_set_chunk(self.h, int(crops)), "mme_set_chunk")

@@ -44,6 +44,7 @@ struct mme_ctx {
     bool loaded = false;
     float ln_eps = 1e-12f;
     int chunk = 1024;
+    int gemm_variant = 0;
     // weights
     std::vector<void*> allocs;
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
@@ -202,7 +203,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
         g.pos = c->pos;
         g.out = c->x.p;
         g.ldo = VIT_D;
-        HIP_TRY(c, launch_gemm(EPI_PATCH, g, s));
+        HIP_TRY(c, launch_gemm(EPI_PATCH, g, s, c->gemm_variant));
     }
     {
         Timed t(c, s, KC_LN);
@@ -219,7 +220,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->hbuf.p; g.W = L.qkv_w; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
             g.bias = L.qkv_b; g.out = c->qkv.p; g.ldo = 3 * VIT_D;
-            HIP_TRY(c, launch_gemm(EPI_BIAS, g, s));
+            HIP_TRY(c, launch_gemm(EPI_BIAS, g, s, c->gemm_variant));
         }
         {
             Timed t(c, s, KC_ATTN);
@@ -230,7 +231,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->att.p; g.W = L.o_w; g.M = M; g.N = VIT_D; g.K = VIT_D;
             g.bias = L.o_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
-            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s));
+            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
         }
         {
             Timed t(c, s, KC_LN);
@@ -241,14 +242,14 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->hbuf.p; g.W = L.fc1_w; g.M = M; g.N = VIT_F; g.K = VIT_D;
             g.bias = L.fc1_b; g.out = c->mlp.p; g.ldo = VIT_F;
-            HIP_TRY(c, launch_gemm(EPI_BIAS_GELU, g, s));
+            HIP_TRY(c, launch_gemm(EPI_BIAS_GELU, g, s, c->gemm_variant));
         }
         {
             Timed t(c, s, KC_GEMM);
             g = GemmArgs{};
             g.A = c->mlp.p; g.W = L.fc2_w; g.M = M; g.N = VIT_D; g.K = VIT_F;
             g.bias = L.fc2_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
-            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s));
+            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
         }
     }
     {
@@ -425,6 +426,13 @@ int mme_set_normalisation(mme_ctx* c, const float mean[3], const float stdv[3]) 
     return set_lut(c, mean, stdv);
 }
 
+int mme_set_gemm_variant(mme_ctx* c, int variant) {
+    if (!c) return MME_E_ARG;
+    if (variant < 0 || variant > 2) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128) or 2 (256x256)");
+    c->gemm_variant = variant;
+    return MME_OK;
+}
+
 int mme_set_chunk(mme_ctx* c, int crops) {
     if (!c) return MME_E_ARG;
     if (crops < 1 || crops > 16384) return fail(c, MME_E_ARG, "mme_set_chunk: %d outside 1..16384", crops);
@@ -513,7 +521,7 @@ int mme_cosine(mme_ctx* c, const uint16_t* a, int m, const uint16_t* b, int n, i
     Timed t(c, s, KC_COS);
     GemmArgs g{};
     g.A = a; g.W = b; g.M = m; g.N = n; g.K = d; g.outf = sim; g.ldf = ld;
-    HIP_TRY(c, launch_gemm(EPI_F32, g, s));
+    HIP_TRY(c, launch_gemm(EPI_F32, g, s, c->gemm_variant));
     return MME_OK;
 }
 

@@ -16,28 +16,13 @@
 //     bias / residual vector loads.
 //   * XCD-aware bijective tile order: consecutive tiles share the A row panel in one XCD's L2.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
-
-// erf-GELU (transformers ACT2FN["gelu"]) with Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7),
-// branch-free; the result is rounded to bf16 (2^-9 relative) right after.
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    float p = 1.061405429f;
-    p = p * t - 1.453152027f;
-    p = p * t + 1.421413741f;
-    p = p * t - 0.284496736f;
-    p = p * t + 0.254829592f;
-    const float e = __expf(-z * z);
-    const float erf_abs = 1.0f - p * t * e;
-    const float erf = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf);
-}
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
@@ -122,56 +107,29 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wr * 64 + i * 16 + fr;
         if (m >= g.M) continue;
-        int64_t orow = m;
-        int prow = 0;
-        if (EPI == EPI_PATCH) {
-            const int b = m / VIT_NP;
-            prow = m - b * VIT_NP + 1;
-            orow = (int64_t)b * VIT_T + prow;
-        }
+        const EpiRow er = epi_row<EPI>(m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + fq * 4;
             if (n >= g.N) continue;
-            f32x4 v = acc[i][j];
-            if (EPI == EPI_F32) {
-                float* o = g.outf + (int64_t)m * g.ldf + n;
-                if (n + 3 < g.N && ((g.ldf & 3) == 0)) {
-                    *(f32x4*)o = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n + r < g.N) o[r] = v[r];
-                }
-                continue;
-            }
-            const f32x4 bv = *(const f32x4*)(g.bias + n);
-            v += bv;
-            if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (EPI == EPI_PATCH) {
-                v += *(const f32x4*)(g.pos + (int64_t)prow * g.N + n);
-            }
-            bf16_t* o = (bf16_t*)g.out + orow * g.ldo + n;
-            if (EPI == EPI_BIAS_RES) {
-                const bf16x4 rv = *(const bf16x4*)((const bf16_t*)g.res + orow * g.ldo + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-            }
-            bf16x4 ov;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
-            *(bf16x4*)o = ov;
+            epi_store<EPI>(g, m, er, n, acc[i][j]);
         }
     }
 }
 
 }  // namespace
 
-hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
+
+// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (variant == 0) {
+        // the 256 kernel wants at least ~2 tiles per CU to amortise its prologue
+        const int64_t tiles256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        variant = tiles256 >= 256 ? 2 : 1;
+    }
+    if (variant == 2) return launch_gemm256(epilogue, g, s);
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

@@ -1,0 +1,218 @@
+// bf16 "TN" GEMM, 256 x 256 x 64 tile, 8 waves -- the large-M kernel of the ViT forward.
+//
+//   C[M,N] = A[M,K] . W[N,K]^T (+ fused epilogue), both operands K-contiguous.
+//
+// Design for CDNA4 (one workgroup of 512 threads per CU, 128 KiB of the 160 KiB LDS):
+//   * 8 waves as 2 (M) x 4 (N); a wave owns 128 x 64 of C = 8 x 4 MFMA 16x16x32 tiles
+//     (128 accumulator VGPRs).  Waves w and w+4 share a SIMD and belong to different M halves.
+//   * The two M halves ("groups") run one barrier apart: while group 0 issues the 16 MFMAs of
+//     a phase, group 1 reads its next fragments from LDS and issues LDS-DMA loads, and vice
+//     versa, so each SIMD's matrix pipe always has one wave feeding it (ping-pong).
+//   * A K-tile (64 deep) is 4 phases = the 4 quadrants (64 x 32) of the wave tile.  B fragments
+//     of both column halves stay in registers for the whole K-tile, A fragments are re-read
+//     per row half: 20 ds_read_b128 per wave per K-tile for 64 MFMAs.
+//   * global -> LDS by LDS-DMA in HALF tiles (128 rows x 64 k = 16 KiB; 2 x 1 KiB pieces per
+//     wave), into a 2-slot ring.  Each phase issues one half tile, ordered so that a region is
+//     re-filled only after the last wave finished reading it:
+//         tile t, q0: B_hi(t+1)   q1: A_lo(t+1)   q2: A_hi(t+1)   q3: B_lo(t+2)
+//     One counted wait per K-tile (`s_waitcnt vmcnt(2)` in q3: everything but the two newest
+//     DMA pieces has landed), followed by a barrier a full phase before the first read of tile
+//     t+1 -- LDS-DMA data is ordered for a ds_read only by the issuer's vmcnt + a barrier.
+//     Loads stay in flight across barriers (raw s_barrier, never __syncthreads).
+//   * LDS image: 128-byte rows, 16-byte chunk index XOR ((row>>1)&7): conflict-free
+//     ds_read_b128 fragment reads; the swizzle is applied to the DMA SOURCE address (the LDS
+//     destination of LDS-DMA is lane-linear).
+//   * Persistent over tiles (grid = #CUs), XCD-aware tile order: the tiles that share an A row
+//     panel run back to back on one XCD, so A is fetched from HBM once and served from L2.
+#include "common.h"
+#include "gemm_epilogue.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int HALF = 128 * TK * 2;  // 16 KiB: 128 rows x 128 B
+constexpr int SLOT = 4 * HALF;      // A_lo | A_hi | B_lo | B_hi
+constexpr int R_ALO = 0, R_AHI = HALF, R_BLO = 2 * HALF, R_BHI = 3 * HALF;
+
+#define S_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fq = lane >> 4, fsw = (lane >> 1) & 7;
+    const int ldb = g.K * 2;
+    const int nk = g.K / TK;
+    const int ntiles = tiles_m * tiles_n;
+
+    // fragment read bases inside a slot
+    const int a_base = wm * HALF + fr * 128;
+    const int b_base = R_BLO + (wn >> 1) * HALF + ((wn & 1) * 64 + fr) * 128;
+    const int ch0 = ((0 + fq) ^ fsw) << 4, ch1 = ((4 + fq) ^ fsw) << 4;
+    // DMA piece geometry of this lane: pieces 2*wave, 2*wave+1 of a half tile
+    const int pr0 = (wave * 2) * 8 + (lane >> 3), pr1 = pr0 + 8;
+    const int pc0 = ((lane & 7) ^ ((pr0 >> 1) & 7)) << 4, pc1 = ((lane & 7) ^ ((pr1 >> 1) & 7)) << 4;
+    char* const dst0 = lds + (wave * 2) * 1024;
+    char* const dst1 = dst0 + 1024;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int id = xcd_remap(tile, ntiles);
+        const int tm = id / tiles_n, tn = id - tm * tiles_n;
+        const int m0 = tm * TM, n0 = tn * TN;
+        const char* Ag = (const char*)g.A + (size_t)m0 * ldb;
+        const char* Wg = (const char*)g.W + (size_t)n0 * ldb;
+        // per-lane source offsets relative to the tile's first row (rows past the edge re-read the last row)
+        const int mrem = g.M - 1 - m0, nrem = g.N - 1 - n0;
+        const int a_lo0 = min(pr0, mrem) * ldb + pc0, a_lo1 = min(pr1, mrem) * ldb + pc1;
+        const int a_hi0 = min(pr0 + 128, mrem) * ldb + pc0, a_hi1 = min(pr1 + 128, mrem) * ldb + pc1;
+        const int b_lo0 = min(pr0, nrem) * ldb + pc0, b_lo1 = min(pr1, nrem) * ldb + pc1;
+        const int b_hi0 = min(pr0 + 128, nrem) * ldb + pc0, b_hi1 = min(pr1 + 128, nrem) * ldb + pc1;
+
+        auto stage = [&](const char* gbase, int off0, int off1, int region) {
+            glds16(gbase + off0, dst0 + region);
+            glds16(gbase + off1, dst1 + region);
+        };
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // prologue: tile 0 completely, plus B_lo of tile 1
+        stage(Wg, b_lo0, b_lo1, R_BLO);
+        stage(Wg, b_hi0, b_hi1, R_BHI);
+        stage(Ag, a_lo0, a_lo1, R_ALO);
+        stage(Ag, a_hi0, a_hi1, R_AHI);
+        if (nk > 1) {
+            stage(Wg + TK * 2, b_lo0, b_lo1, SLOT + R_BLO);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        S_BARRIER();
+        if (wm == 1) S_BARRIER();  // group 1 runs one barrier behind group 0
+
+        bf16x8 fa[4][2], fb[4][2];
+
+#define READ_B(slot_off, n_first)                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+        fb[(n_first) + j][0] = *(const bf16x8*)(lds + (slot_off) + b_base + ((n_first) + j) * 2048 + ch0); \
+        fb[(n_first) + j][1] = *(const bf16x8*)(lds + (slot_off) + b_base + ((n_first) + j) * 2048 + ch1); \
+    }
+#define READ_A(slot_off, m_first)                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
+        fa[i][0] = *(const bf16x8*)(lds + (slot_off) + a_base + ((m_first) + i) * 2048 + ch0); \
+        fa[i][1] = *(const bf16x8*)(lds + (slot_off) + a_base + ((m_first) + i) * 2048 + ch1); \
+    }
+#define MFMA_QUAD(m_first, n_first)                                                            \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                              \
+        acc[(m_first) + i][(n_first) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(          \
+            fb[(n_first) + j][ks], fa[i][ks], acc[(m_first) + i][(n_first) + j], 0, 0, 0);     \
+    __builtin_amdgcn_s_setprio(0);
+
+#define K_TILE(cur, nxt)                                                                       \
+    {                                                                                          \
+        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;                                       \
+        const char* a1 = Ag + (size_t)(t + 1) * (TK * 2);                                      \
+        const char* w1 = Wg + (size_t)(t + 1) * (TK * 2);                                      \
+        /* q0 */                                                                               \
+        READ_B(cur, 0)                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        READ_A(cur, 0)                                                                         \
+        if (has1) stage(w1, b_hi0, b_hi1, (nxt) + R_BHI);                                      \
+        S_BARRIER();                                                                           \
+        MFMA_QUAD(0, 0)                                                                        \
+        S_BARRIER();                                                                           \
+        /* q1 */                                                                               \
+        READ_B(cur, 2)                                                                         \
+        if (has1) stage(a1, a_lo0, a_lo1, (nxt) + R_ALO);                                      \
+        S_BARRIER();                                                                           \
+        MFMA_QUAD(0, 2)                                                                        \
+        S_BARRIER();                                                                           \
+        /* q2 */                                                                               \
+        READ_A(cur, 4)                                                                         \
+        if (has1) stage(a1, a_hi0, a_hi1, (nxt) + R_AHI);                                      \
+        S_BARRIER();                                                                           \
+        MFMA_QUAD(4, 2)                                                                        \
+        S_BARRIER();                                                                           \
+        /* q3 */                                                                               \
+        if (has2) {                                                                            \
+            stage(w1 + TK * 2, b_lo0, b_lo1, (cur) + R_BLO);                                   \
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                   \
+        } else {                                                                               \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+        }                                                                                      \
+        S_BARRIER();                                                                           \
+        MFMA_QUAD(4, 0)                                                                        \
+        S_BARRIER();                                                                           \
+    }
+
+        int t = 0;
+        for (; t + 1 < nk; t += 2) {
+            K_TILE(0, SLOT)
+            ++t;
+            K_TILE(SLOT, 0)
+            --t;
+        }
+        if (t < nk) K_TILE(0, SLOT)
+        if (wm == 0) S_BARRIER();
+
+        // epilogue: acc[i][j][r] is C[m0 + wm*128 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + wm * 128 + i * 16 + fr;
+            if (m >= g.M) continue;
+            const EpiRow er = epi_row<EPI>(m);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                if (n >= g.N) continue;
+                epi_store<EPI>(g, m, er, n, acc[i][j]);
+            }
+        }
+        // every LDS read of this tile completed before the last barriers; the stores above are
+        // drained by the next prologue's vmcnt wait
+    }
+#undef READ_A
+#undef READ_B
+#undef MFMA_QUAD
+#undef K_TILE
+}
+
+template <int EPI>
+hipError_t launch256(const GemmArgs& g, hipStream_t s) {
+    static bool attr_set = false;
+    const int smem = 2 * SLOT;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_256<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
+    const int ntiles = tiles_m * tiles_n;
+    const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
+    hipLaunchKernelGGL(gemm_bf16_tn_256<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    if (g.K <= 0 || (g.K % TK) != 0) return hipErrorInvalidValue;
+    switch (epilogue) {
+        case EPI_BIAS: return launch256<EPI_BIAS>(g, s);
+        case EPI_BIAS_GELU: return launch256<EPI_BIAS_GELU>(g, s);
+        case EPI_BIAS_RES: return launch256<EPI_BIAS_RES>(g, s);
+        case EPI_PATCH: return launch256<EPI_PATCH>(g, s);
+        case EPI_F32: return launch256<EPI_F32>(g, s);
+        default: return hipErrorInvalidValue;
+    }
+}

@@ -1,0 +1,72 @@
+// Fused GEMM epilogues shared by the 128x128 and 256x256 MFMA kernels.
+//
+// A lane always owns 4 consecutive output columns n..n+3 of one row m (operands are fed to
+// the MFMA swapped so that the accumulator's register index runs along n): bias / residual /
+// position vectors load as one 16- or 8-byte vector and the result stores as bf16x4 (8 B) or
+// f32x4 (16 B).
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+// erf-GELU (transformers ACT2FN["gelu"], modeling_vit.py:241-255) with Abramowitz-Stegun
+// 7.1.26 (|err| < 1.5e-7), branch-free; the result is rounded to bf16 (2^-9 relative).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = __expf(-z * z);
+    const float erf_abs = 1.0f - p * t * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
+struct EpiRow {
+    int64_t orow;  // output row (EPI_PATCH remaps patch rows past the [CLS] rows)
+    int prow;      // position row for EPI_PATCH
+};
+
+template <int EPI>
+__device__ __forceinline__ EpiRow epi_row(int m) {
+    EpiRow r{m, 0};
+    if (EPI == EPI_PATCH) {
+        const int b = m / VIT_NP;
+        r.prow = m - b * VIT_NP + 1;
+        r.orow = (int64_t)b * VIT_T + r.prow;
+    }
+    return r;
+}
+
+// v = accumulator values for (m, n..n+3); n < N and n % 4 == 0 guaranteed by the caller.
+template <int EPI>
+__device__ __forceinline__ void epi_store(const GemmArgs& g, int m, const EpiRow& er, int n, f32x4 v) {
+    if (EPI == EPI_F32) {
+        float* o = g.outf + (int64_t)m * g.ldf + n;
+        if (n + 3 < g.N && ((g.ldf & 3) == 0)) {
+            *(f32x4*)o = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < g.N) o[r] = v[r];
+        }
+        return;
+    }
+    v += *(const f32x4*)(g.bias + n);
+    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    }
+    if (EPI == EPI_PATCH) v += *(const f32x4*)(g.pos + (int64_t)er.prow * g.N + n);
+    bf16_t* o = (bf16_t*)g.out + er.orow * g.ldo + n;
+    if (EPI == EPI_BIAS_RES) {
+        const bf16x4 rv = *(const bf16x4*)((const bf16_t*)g.res + er.orow * g.ldo + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    bf16x4 ov;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
+    *(bf16x4*)o = ov;
+}
