@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--crops", type=int, default=CROPS_PER_GPU, help="crops per GPU (headline config: 4096)")
     ap.add_argument("--chunk", type=int, default=0, help="crops per encoder pass (0 = library default)")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="0 auto, 1 128x128, 2 256 ping-pong, 3 256 streaming")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -96,6 +97,8 @@ def main():
     eng.load_vit(weights)
     if args.chunk:
         eng.set_chunk(args.chunk)
+    if args.gemm_variant:
+        eng.set_gemm_variant(args.gemm_variant)
 
     n = args.crops
     start = rank * n

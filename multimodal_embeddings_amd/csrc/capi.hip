@@ -428,7 +428,7 @@ int mme_set_normalisation(mme_ctx* c, const float mean[3], const float stdv[3]) 
 
 int mme_set_gemm_variant(mme_ctx* c, int variant) {
     if (!c) return MME_E_ARG;
-    if (variant < 0 || variant > 2) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128) or 2 (256x256)");
+    if (variant < 0 || variant > 3) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256 ping-pong) or 3 (256x256 streaming)");
     c->gemm_variant = variant;
     return MME_OK;
 }

@@ -120,8 +120,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
 }  // namespace
 
 hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s);
 
-// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel
+// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel, 3 = 256x256 streaming kernel
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (variant == 0) {
@@ -130,6 +131,10 @@ hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int varia
         variant = tiles256 >= 256 ? 2 : 1;
     }
     if (variant == 2) return launch_gemm256(epilogue, g, s);
+    if (variant == 3) {
+        // the streaming kernel needs an even number of K-tiles; otherwise the ping-pong kernel serves
+        return (g.K % 128) == 0 ? launch_gemm256s(epilogue, g, s) : launch_gemm256(epilogue, g, s);
+    }
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

@@ -13,8 +13,9 @@
 //     per row half: 20 ds_read_b128 per wave per K-tile for 64 MFMAs.
 //   * global -> LDS by LDS-DMA in HALF tiles (128 rows x 64 k = 16 KiB; 2 x 1 KiB pieces per
 //     wave), into a 2-slot ring.  Each phase issues one half tile, ordered so that a region is
-//     re-filled only after the last wave finished reading it:
-//         tile t, q0: B_hi(t+1)   q1: A_lo(t+1)   q2: A_hi(t+1)   q3: B_lo(t+2)
+//     re-filled only after the last wave finished reading it (activations first: they come from
+//     HBM / Infinity Cache and need the longest lead, the weights are L2 resident):
+//         tile t, q0: A_lo(t+1)   q1: A_hi(t+1)   q2: B_hi(t+1)   q3: B_lo(t+2)
 //     One counted wait per K-tile (`s_waitcnt vmcnt(2)` in q3: everything but the two newest
 //     DMA pieces has landed), followed by a barrier a full phase before the first read of tile
 //     t+1 -- LDS-DMA data is ordered for a ds_read only by the issuer's vmcnt + a barrier.
@@ -24,6 +25,11 @@
 //     destination of LDS-DMA is lane-linear).
 //   * Persistent over tiles (grid = #CUs), XCD-aware tile order: the tiles that share an A row
 //     panel run back to back on one XCD, so A is fetched from HBM once and served from L2.
+//     The next tile's first K-tile is requested BEFORE the epilogue of the current one, so the
+//     epilogue's loads/stores and the prologue latency overlap (K is only 12 K-tiles deep for
+//     three of the four ViT GEMM shapes, so per-tile overhead matters as much as the main loop).
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -38,7 +44,7 @@ constexpr int R_ALO = 0, R_AHI = HALF, R_BLO = 2 * HALF, R_BHI = 3 * HALF;
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles_m, int tiles_n, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,23 +64,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
     char* const dst0 = lds + (wave * 2) * 1024;
     char* const dst1 = dst0 + 1024;
 
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Per-tile state is wave-uniform (SGPRs); the per-lane DMA source offset of a piece is
+    // recomputed per use (one v_min + one v_mad) instead of living in 8 VGPRs across the epilogue.
+    struct TileCtx {
+        int m0, n0, mrem, nrem;
+        const char *Ag, *Wg;
+    };
+    auto make_ctx = [&](int tile) {
+        TileCtx c;
         const int id = xcd_remap(tile, ntiles);
         const int tm = id / tiles_n, tn = id - tm * tiles_n;
-        const int m0 = tm * TM, n0 = tn * TN;
-        const char* Ag = (const char*)g.A + (size_t)m0 * ldb;
-        const char* Wg = (const char*)g.W + (size_t)n0 * ldb;
-        // per-lane source offsets relative to the tile's first row (rows past the edge re-read the last row)
-        const int mrem = g.M - 1 - m0, nrem = g.N - 1 - n0;
-        const int a_lo0 = min(pr0, mrem) * ldb + pc0, a_lo1 = min(pr1, mrem) * ldb + pc1;
-        const int a_hi0 = min(pr0 + 128, mrem) * ldb + pc0, a_hi1 = min(pr1 + 128, mrem) * ldb + pc1;
-        const int b_lo0 = min(pr0, nrem) * ldb + pc0, b_lo1 = min(pr1, nrem) * ldb + pc1;
-        const int b_hi0 = min(pr0 + 128, nrem) * ldb + pc0, b_hi1 = min(pr1 + 128, nrem) * ldb + pc1;
+        c.m0 = tm * TM;
+        c.n0 = tn * TN;
+        c.Ag = (const char*)g.A + (size_t)(dbg == 2 ? 0 : c.m0) * ldb;
+        c.Wg = (const char*)g.W + (size_t)(dbg == 2 ? 0 : c.n0) * ldb;
+        c.mrem = g.M - 1 - c.m0;  // rows past the matrix edge re-read the last row
+        c.nrem = g.N - 1 - c.n0;
+        return c;
+    };
+    // one half tile = 128 rows: pieces 2*wave and 2*wave+1; `rem` clamps the row, `half` = 0/128
+    auto stage = [&](const char* gbase, int rem, int half, int region) {
+        glds16(gbase + (min(pr0 + half, rem) * ldb + pc0), dst0 + region);
+        glds16(gbase + (min(pr1 + half, rem) * ldb + pc1), dst1 + region);
+    };
+    // K-tile 0 completely, plus B_lo of K-tile 1 (10 DMA pieces per wave)
+    auto issue_prologue = [&](const TileCtx& c) {
+        stage(c.Ag, c.mrem, 0, R_ALO);
+        stage(c.Ag, c.mrem, 128, R_AHI);
+        stage(c.Wg, c.nrem, 0, R_BLO);
+        stage(c.Wg, c.nrem, 128, R_BHI);
+        if (nk > 1) stage(c.Wg + TK * 2, c.nrem, 0, SLOT + R_BLO);
+    };
 
-        auto stage = [&](const char* gbase, int off0, int off1, int region) {
-            glds16(gbase + off0, dst0 + region);
-            glds16(gbase + off1, dst1 + region);
-        };
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    TileCtx cx = make_ctx(tile);
+    issue_prologue(cx);
+    bool stores_pending = false;  // the previous tile's 32 epilogue stores may still be in flight
+
+    while (true) {
+        const int m0 = cx.m0, n0 = cx.n0, mrem = cx.mrem, nrem = cx.nrem;
+        const char* Ag = cx.Ag;
+        const char* Wg = cx.Wg;
 
         f32x4 acc[8][4];
 #pragma unroll
@@ -82,13 +113,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // prologue: tile 0 completely, plus B_lo of tile 1
-        stage(Wg, b_lo0, b_lo1, R_BLO);
-        stage(Wg, b_hi0, b_hi1, R_BHI);
-        stage(Ag, a_lo0, a_lo1, R_ALO);
-        stage(Ag, a_hi0, a_hi1, R_AHI);
-        if (nk > 1) {
-            stage(Wg + TK * 2, b_lo0, b_lo1, SLOT + R_BLO);
+        // K-tile 0 must have landed; B_lo of K-tile 1 (2 pieces) and the previous tile's stores
+        // (younger than every prologue piece: vmcnt retires in issue order) may stay in flight.
+        if (stores_pending) {
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        } else if (nk > 1) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -119,32 +148,32 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
 
 #define K_TILE(cur, nxt)                                                                       \
     {                                                                                          \
-        const bool has1 = t + 1 < nk, has2 = t + 2 < nk;                                       \
+        const bool has1 = t + 1 < nk && dbg != 1, has2 = t + 2 < nk && dbg != 1;               \
         const char* a1 = Ag + (size_t)(t + 1) * (TK * 2);                                      \
         const char* w1 = Wg + (size_t)(t + 1) * (TK * 2);                                      \
         /* q0 */                                                                               \
         READ_B(cur, 0)                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         READ_A(cur, 0)                                                                         \
-        if (has1) stage(w1, b_hi0, b_hi1, (nxt) + R_BHI);                                      \
+        if (has1) stage(a1, mrem, 0, (nxt) + R_ALO);                                        \
         S_BARRIER();                                                                           \
         MFMA_QUAD(0, 0)                                                                        \
         S_BARRIER();                                                                           \
         /* q1 */                                                                               \
         READ_B(cur, 2)                                                                         \
-        if (has1) stage(a1, a_lo0, a_lo1, (nxt) + R_ALO);                                      \
+        if (has1) stage(a1, mrem, 128, (nxt) + R_AHI);                                      \
         S_BARRIER();                                                                           \
         MFMA_QUAD(0, 2)                                                                        \
         S_BARRIER();                                                                           \
         /* q2 */                                                                               \
         READ_A(cur, 4)                                                                         \
-        if (has1) stage(a1, a_hi0, a_hi1, (nxt) + R_AHI);                                      \
+        if (has1) stage(w1, nrem, 128, (nxt) + R_BHI);                                      \
         S_BARRIER();                                                                           \
         MFMA_QUAD(4, 2)                                                                        \
         S_BARRIER();                                                                           \
         /* q3 */                                                                               \
         if (has2) {                                                                            \
-            stage(w1 + TK * 2, b_lo0, b_lo1, (cur) + R_BLO);                                   \
+            stage(w1 + TK * 2, nrem, 0, (cur) + R_BLO);                                     \
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                   \
         } else {                                                                               \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
@@ -164,21 +193,84 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
         if (t < nk) K_TILE(0, SLOT)
         if (wm == 0) S_BARRIER();
 
-        // epilogue: acc[i][j][r] is C[m0 + wm*128 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
+        // Every LDS read of this tile is complete: stream the next tile's first K-tile in while
+        // the epilogue below runs (its loads and stores are younger, see the wait above).
+        const int next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < ntiles;
+        if (has_next) {
+            cx = make_ctx(next_tile);
+            issue_prologue(cx);
+        }
+        bool interior = false;
+
+        // epilogue: acc[i][j][r] is C[m0 + wm*128 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r].
+        // vmcnt counts stores too on CDNA4, so a load inside the store loop would wait for every
+        // store issued before it: all loads (bias, residual, positions) are issued first, with
+        // row indices clamped instead of branched, and the stores are fire-and-forget.
+        if (EPI != EPI_F32 && n0 + TN <= g.N && m0 + TM <= g.M) {
+            interior = true;
+            // interior tile: straight-line code, no per-lane predicate (a branch would make the
+            // compiler re-insert vmcnt(0) -- i.e. a wait for the stores -- at every join)
+            const int nb = n0 + wn * 64 + fq * 4;
+            const int mb = m0 + wm * 128 + fr;
+            f32x4 bv[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + wm * 128 + i * 16 + fr;
-            if (m >= g.M) continue;
-            const EpiRow er = epi_row<EPI>(m);
+            for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nb + j * 16);
+            constexpr int IH = (EPI == EPI_PATCH) ? 2 : 8;  // rows of 16 handled per load batch
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + fq * 4;
-                if (n >= g.N) continue;
-                epi_store<EPI>(g, m, er, n, acc[i][j]);
+            for (int i0 = 0; i0 < 8; i0 += IH) {
+                EpiRow er[IH];
+                bf16x4 rv[EPI == EPI_BIAS_RES ? IH : 1][4];
+                f32x4 pv[EPI == EPI_PATCH ? IH : 1][4];
+#pragma unroll
+                for (int i = 0; i < IH; ++i) {
+                    er[i] = epi_row<EPI>(mb + (i0 + i) * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (EPI == EPI_BIAS_RES)
+                            rv[i][j] = *(const bf16x4*)((const bf16_t*)g.res + er[i].orow * g.ldo + nb + j * 16);
+                        if (EPI == EPI_PATCH) pv[i][j] = *(const f32x4*)(g.pos + (int64_t)er[i].prow * g.N + nb + j * 16);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < IH; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[i0 + i][j] + bv[j];
+                        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        }
+                        if (EPI == EPI_PATCH) v += pv[i][j];
+                        if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+                        }
+                        bf16x4 ov;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
+                        *(bf16x4*)((bf16_t*)g.out + er[i].orow * g.ldo + nb + j * 16) = ov;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + fr;
+                if (m >= g.M) continue;
+                const EpiRow er = epi_row<EPI>(m);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + fq * 4;
+                    if (n >= g.N) continue;
+                    epi_store<EPI>(g, m, er, n, acc[i][j]);
+                }
             }
         }
-        // every LDS read of this tile completed before the last barriers; the stores above are
-        // drained by the next prologue's vmcnt wait
+        if (!has_next) break;
+        if (!interior) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unknown store count: drain
+        stores_pending = interior;
+        tile = next_tile;
     }
 #undef READ_A
 #undef READ_B
@@ -198,7 +290,8 @@ hipError_t launch256(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
-    hipLaunchKernelGGL(gemm_bf16_tn_256<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n);
+    static const int dbg = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;  // timing experiments only
+    hipLaunchKernelGGL(gemm_bf16_tn_256<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, dbg);
     return hipGetLastError();
 }
 

@@ -176,7 +176,7 @@ def test_embed_chunking_and_ragged_batch(engine):
     assert e0.shape == (0, 768)
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_cosine_matches_f64(engine, variant):
     engine.set_gemm_variant(variant)
     rng = np.random.default_rng(2)
@@ -208,18 +208,29 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
         b = engine.normalise_rows(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda())
         engine.set_gemm_variant(1)
         ref = engine.cosine(a, b)
-        engine.set_gemm_variant(2)
-        for _ in range(reps):
-            got = engine.cosine(a, b)
-            assert torch.equal(got, ref), (m, n, d)
+        for variant in (2, 3):
+            engine.set_gemm_variant(variant)
+            for _ in range(reps):
+                got = engine.cosine(a, b)
+                assert torch.equal(got, ref), (variant, m, n, d)
     arrays, _ = _golden_crops(golden_dir)
     pix, offs, hw = _pack(arrays)
     engine.set_gemm_variant(1)
     e1, _ = engine.embed(pix, offs, hw)
-    engine.set_gemm_variant(2)
-    for _ in range(3):
-        e2, _ = engine.embed(pix, offs, hw)
-        assert torch.equal(e1, e2)
+    for variant in (2, 3):
+        engine.set_gemm_variant(variant)
+        for _ in range(3):
+            e2, _ = engine.embed(pix, offs, hw)
+            assert torch.equal(e1, e2), variant
+    # a batch large enough for several output tiles per workgroup (K-tile stream across tiles)
+    crops = synthetic_crops(300, seed=5)
+    pixb, offsb, hwb = _pack(list(crops))
+    engine.set_gemm_variant(1)
+    r1, _ = engine.embed(pixb, offsb, hwb)
+    for variant in (2, 3):
+        engine.set_gemm_variant(variant)
+        r2, _ = engine.embed(pixb, offsb, hwb)
+        assert torch.equal(r1, r2), variant
     engine.set_gemm_variant(0)
 
 
