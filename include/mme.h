@@ -165,6 +165,14 @@ int mme_page_similarity(mme_ctx* ctx, const uint16_t* emb_dev, int64_t N, int d,
 int mme_cluster_pages(mme_ctx* ctx, const double* S_dev, int P, int n_clusters, int mode, int32_t* labels_dev,
                       int32_t* k_dev, double* scores_dev, void* stream);
 
+/* Diagnostic: time one MFMA GEMM shape on random bf16 data (allocates its own operands;
+ * synchronous).  epilogue 0 bias, 1 bias+GELU, 2 bias+residual, 3 patch-embed, 4 f32 out;
+ * variant as mme_set_gemm_variant.  stamps_host (optional, uint64[stamps_words]): in-kernel cycle
+ * stamps of the streaming kernel, 8 words per wave: total, LDS-drain, DMA-wait, barrier, epilogue
+ * cycles and K-tile count. */
+int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms,
+                   uint64_t* stamps_host, int stamps_words);
+
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
  * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster */
 #define MME_NUM_KERNEL_CLASSES 8

@@ -120,10 +120,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
 }  // namespace
 
 hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
-hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s, unsigned long long* stamps);
+hipError_t launch_gemm256x128(int epilogue, const GemmArgs& g, hipStream_t s);
 
-// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel, 3 = 256x256 streaming kernel
-hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
+// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel, 3 = 256x256 streaming kernel, 4 = 256x128 two-workgroups-per-CU kernel
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant, unsigned long long* stamps) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (variant == 0) {
         // the 256 kernel wants at least ~2 tiles per CU to amortise its prologue
@@ -131,9 +132,10 @@ hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int varia
         variant = tiles256 >= 256 ? 2 : 1;
     }
     if (variant == 2) return launch_gemm256(epilogue, g, s);
+    if (variant == 4) return (g.K % 64) == 0 ? launch_gemm256x128(epilogue, g, s) : launch_gemm256(epilogue, g, s);
     if (variant == 3) {
         // the streaming kernel needs an even number of K-tiles; otherwise the ping-pong kernel serves
-        return (g.K % 128) == 0 ? launch_gemm256s(epilogue, g, s) : launch_gemm256(epilogue, g, s);
+        return (g.K % 128) == 0 ? launch_gemm256s(epilogue, g, s, stamps) : launch_gemm256(epilogue, g, s);
     }
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
     if (tile >= ntiles) return;
     TileCtx cx = make_ctx(tile);
     issue_prologue(cx);
-    bool stores_pending = false;  // the previous tile's 32 epilogue stores may still be in flight
+    bool stores_pending = false;  // the previous tile's 16 epilogue stores may still be in flight
 
     while (true) {
         const int m0 = cx.m0, n0 = cx.n0, mrem = cx.mrem, nrem = cx.nrem;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
         // K-tile 0 must have landed; B_lo of K-tile 1 (2 pieces) and the previous tile's stores
         // (younger than every prologue piece: vmcnt retires in issue order) may stay in flight.
         if (stores_pending) {
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         } else if (nk > 1) {
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         } else {
@@ -211,45 +211,66 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
             interior = true;
             // interior tile: straight-line code, no per-lane predicate (a branch would make the
             // compiler re-insert vmcnt(0) -- i.e. a wait for the stores -- at every join)
-            const int nb = n0 + wn * 64 + fq * 4;
-            const int mb = m0 + wm * 128 + fr;
-            f32x4 bv[4];
+            if constexpr (EPI == EPI_PATCH) {
+                const int nb = n0 + wn * 64 + fq * 4;
+                const int mb = m0 + wm * 128 + fr;
+                f32x4 bv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nb + j * 16);
-            constexpr int IH = (EPI == EPI_PATCH) ? 2 : 8;  // rows of 16 handled per load batch
+                for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nb + j * 16);
 #pragma unroll
-            for (int i0 = 0; i0 < 8; i0 += IH) {
-                EpiRow er[IH];
-                bf16x4 rv[EPI == EPI_BIAS_RES ? IH : 1][4];
-                f32x4 pv[EPI == EPI_PATCH ? IH : 1][4];
+                for (int i0 = 0; i0 < 8; i0 += 2) {
+                    EpiRow er[2];
+                    f32x4 pv[2][4];
 #pragma unroll
-                for (int i = 0; i < IH; ++i) {
-                    er[i] = epi_row<EPI>(mb + (i0 + i) * 16);
+                    for (int i = 0; i < 2; ++i) {
+                        er[i] = epi_row<EPI>(mb + (i0 + i) * 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (EPI == EPI_BIAS_RES)
-                            rv[i][j] = *(const bf16x4*)((const bf16_t*)g.res + er[i].orow * g.ldo + nb + j * 16);
-                        if (EPI == EPI_PATCH) pv[i][j] = *(const f32x4*)(g.pos + (int64_t)er[i].prow * g.N + nb + j * 16);
+                        for (int j = 0; j < 4; ++j) pv[i][j] = *(const f32x4*)(g.pos + (int64_t)er[i].prow * g.N + nb + j * 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x4 v = acc[i0 + i][j] + bv[j] + pv[i][j];
+                            *(uint2*)((bf16_t*)g.out + er[i].orow * g.ldo + nb + j * 16) = pack_bf16x4(v);
+                        }
+                }
+            } else {
+                // 16-byte accesses (gemm_epilogue.h), wave-uniform row bases + 32-bit lane offsets
+                const int64_t tile_off = (int64_t)(m0 + wm * 128) * g.ldo + n0 + wn * 64;
+                const int lo0 = fr * (int)g.ldo + row16_col(0, fq), lo1 = fr * (int)g.ldo + row16_col(2, fq);
+                const bf16_t* resb = (const bf16_t*)g.res + tile_off;
+                bf16_t* outb = (bf16_t*)g.out + tile_off;
+                f32x4 bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + n0 + wn * 64 + fq * 4 + j * 16);
+                uint4 rv[EPI == EPI_BIAS_RES ? 8 : 1][2];
+                if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        rv[i][0] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo0);
+                        rv[i][1] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo1);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < IH; ++i) {
+                for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 v = acc[i0 + i][j] + bv[j];
+                    for (int jp = 0; jp < 4; jp += 2) {
+                        f32x4 v0 = acc[i][jp] + bv[jp], v1 = acc[i][jp + 1] + bv[jp + 1];
                         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                            for (int r = 0; r < 4; ++r) {
+                                v0[r] = gelu_erf(v0[r]);
+                                v1[r] = gelu_erf(v1[r]);
+                            }
                         }
-                        if (EPI == EPI_PATCH) v += pv[i][j];
                         if (EPI == EPI_BIAS_RES) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+                            uint2 rp, rq;
+                            row16_to_pair(rv[i][jp >> 1], rp, rq);
+                            v0 += unpack_bf16x4(rp);
+                            v1 += unpack_bf16x4(rq);
                         }
-                        bf16x4 ov;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
-                        *(bf16x4*)((bf16_t*)g.out + er[i].orow * g.ldo + nb + j * 16) = ov;
+                        *(uint4*)(outb + (int64_t)i * 16 * g.ldo + (jp ? lo1 : lo0)) = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
                     }
                 }
             }
@@ -269,7 +290,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
         }
         if (!has_next) break;
         if (!interior) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unknown store count: drain
-        stores_pending = interior;
+        stores_pending = interior && EPI != EPI_PATCH;
+        if (interior && EPI == EPI_PATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tile = next_tile;
     }
 #undef READ_A

@@ -31,7 +31,7 @@
 //     of K-tile s only after the barrier that follows the last read of s (sub-phase 5).
 //   * at an output-tile boundary the epilogue's loads are issued BEFORE the DMA of that step and
 //     its stores after it: vmcnt retires in order, so the epilogue never waits for DMA it does
-//     not need, and the next barrier's wait (vmcnt(32)) leaves exactly the 32 stores in flight.
+//     not need, and the next barrier's wait (vmcnt(16)) leaves exactly the 16 stores in flight.
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -49,7 +49,7 @@ constexpr int R_ALO = 0, R_AHI = HALF, R_BLO = 4 * HALF, R_BHI = 5 * HALF;
 #define PHASE_FENCE() asm volatile("" ::: "memory")
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tiles_m, int tiles_n, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,27 +158,28 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
     READ_B(bN1, 0, 2, ch0)
     bool pending_stores = false;  // an interior epilogue's 32 stores may still be in flight
 
-    constexpr int PEND = 32;
-    // Interior-tile epilogue: [bias/residual loads] [DMA of K-tile s+2] [32 stores].  The stores
+    constexpr int PEND = 16;
+    // Interior-tile epilogue: [bias/residual loads] [DMA of K-tile s+2] [16 stores].  The stores
     // are then exactly the PEND youngest vector-memory operations of the wave.
     auto epilogue = [&](int nxt_slot_unused, int cur_slot) {
         const int m0 = cc.m0, n0 = cc.n0;
         if (EPI != EPI_F32 && EPI != EPI_PATCH && n0 + TN <= g.N && m0 + TM <= g.M) {
-            // wave-uniform row bases (SGPR pairs) + one 32-bit lane offset: saddr addressing, no
-            // per-element 64-bit address registers
+            // wave-uniform row bases (SGPR pairs) + 32-bit lane offsets: saddr addressing.  All
+            // accesses are 16 bytes per lane (see gemm_epilogue.h): 16 stores per wave.
             const int64_t tile_off = (int64_t)(m0 + wm * 128) * g.ldo + n0 + wn * 64;
-            const int lane_off = fr * (int)g.ldo + fq * 4;
+            const int lo0 = fr * (int)g.ldo + row16_col(0, fq), lo1 = fr * (int)g.ldo + row16_col(2, fq);
             const bf16_t* resb = (const bf16_t*)g.res + tile_off;
             bf16_t* outb = (bf16_t*)g.out + tile_off;
             f32x4 bv[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + n0 + wn * 64 + fq * 4 + j * 16);
-            bf16x4 rv[EPI == EPI_BIAS_RES ? 8 : 1][4];
+            uint4 rv[EPI == EPI_BIAS_RES ? 8 : 1][2];
             if (EPI == EPI_BIAS_RES) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[i][j] = *(const bf16x4*)(resb + (int64_t)i * 16 * g.ldo + lane_off + j * 16);
+                for (int i = 0; i < 8; ++i) {
+                    rv[i][0] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo0);
+                    rv[i][1] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo1);
+                }
             }
             PHASE_FENCE();
             load_A(l2, cur_slot);
@@ -188,20 +189,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 v = acc[i][j] + bv[j];
+                for (int jp = 0; jp < 4; jp += 2) {
+                    f32x4 v0 = acc[i][jp] + bv[jp], v1 = acc[i][jp + 1] + bv[jp + 1];
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                        for (int r = 0; r < 4; ++r) {
+                            v0[r] = gelu_erf(v0[r]);
+                            v1[r] = gelu_erf(v1[r]);
+                        }
                     }
                     if (EPI == EPI_BIAS_RES) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)rv[i][j][r];
+                        uint2 rp, rq;
+                        row16_to_pair(rv[i][jp >> 1], rp, rq);
+                        v0 += unpack_bf16x4(rp);
+                        v1 += unpack_bf16x4(rq);
                     }
-                    bf16x4 ov;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
-                    *(bf16x4*)(outb + (int64_t)i * 16 * g.ldo + lane_off + j * 16) = ov;
+                    *(uint4*)(outb + (int64_t)i * 16 * g.ldo + (jp ? lo1 : lo0)) = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
                 }
             }
             pending_stores = true;
@@ -251,15 +254,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
         PHASE_FENCE();                                                                               \
         /* 6 */                                                                                      \
         MFMA8(aP, bN1, 0, 2)                                                                         \
+        STAMP(t0)                                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+        STAMP(t1)                                                                                    \
         if (pending_stores) {                                                                        \
-            static_assert(PEND == 32, "vmcnt literal below");                                        \
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                                        \
+            static_assert(PEND == 16, "vmcnt literal below");                                        \
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                                        \
             pending_stores = false;                                                                  \
         } else {                                                                                     \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
         }                                                                                            \
+        STAMP(t2)                                                                                    \
         S_BARRIER();                                                                                 \
+        STAMP(t3)                                                                                    \
+        if (stamps) {                                                                                \
+            acc_lds += t1 - t0;                                                                      \
+            acc_vm += t2 - t1;                                                                       \
+            acc_bar += t3 - t2;                                                                      \
+            ++n_kt;                                                                                  \
+        }                                                                                            \
         /* 7 */                                                                                      \
         if (!(LAST)) {                                                                               \
             READ_A(aP, NXT, 0, ch0)                                                                  \
@@ -279,6 +292,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
         if (!(LAST)) advance(l2);                                                                    \
     }
 
+    // diagnostic stamps (off unless a buffer is passed): where a K-tile's sync point spends its time
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, acc_lds = 0, acc_vm = 0, acc_bar = 0, n_kt = 0, t_begin = 0, t_epi = 0, te0 = 0;
+#define STAMP(var) if (stamps) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); }
+    STAMP(t_begin)
     // nk is even (checked by the launcher), so every output tile starts in slot 0
     for (int ti = 0; ti < my_tiles; ++ti) {
 #pragma unroll
@@ -291,7 +308,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
         }
         K_TILE(0, SLOT, false)
         K_TILE(SLOT, 0, true)
+        STAMP(te0)
         epilogue(0, SLOT);  // K-tile s+2 of the stream goes to the slot of the last K-tile (slot 1)
+        STAMP(t0)
+        if (stamps) t_epi += t0 - te0;
         advance(l2);
         seek(cc, cc.tile + (int)gridDim.x);
         if (ti + 1 < my_tiles) {
@@ -300,6 +320,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
             READ_B(bN1, 0, 2, ch0)
         }
     }
+    if (stamps) {
+        STAMP(t0)
+        if (lane == 0) {
+            unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = t0 - t_begin;
+            o[1] = acc_lds;
+            o[2] = acc_vm;
+            o[3] = acc_bar;
+            o[4] = t_epi;
+            o[5] = n_kt;
+        }
+    }
+#undef STAMP
 #undef READ_A
 #undef READ_B
 #undef MFMA8
@@ -307,7 +340,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
 }
 
 template <int EPI>
-hipError_t launch256s(const GemmArgs& g, hipStream_t s) {
+hipError_t launch256s(const GemmArgs& g, hipStream_t s, unsigned long long* stamps) {
     static bool attr_set = false;
     const int smem = 8 * HALF;
     if (!attr_set) {
@@ -318,21 +351,21 @@ hipError_t launch256s(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(gemm_bf16_tn_256s<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n);
+    hipLaunchKernelGGL(gemm_bf16_tn_256s<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, stamps);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s, unsigned long long* stamps) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K <= 0 || (g.K % (2 * TK)) != 0) return hipErrorInvalidValue;  // even number of K-tiles
     switch (epilogue) {
-        case EPI_BIAS: return launch256s<EPI_BIAS>(g, s);
-        case EPI_BIAS_GELU: return launch256s<EPI_BIAS_GELU>(g, s);
-        case EPI_BIAS_RES: return launch256s<EPI_BIAS_RES>(g, s);
-        case EPI_PATCH: return launch256s<EPI_PATCH>(g, s);
-        case EPI_F32: return launch256s<EPI_F32>(g, s);
+        case EPI_BIAS: return launch256s<EPI_BIAS>(g, s, stamps);
+        case EPI_BIAS_GELU: return launch256s<EPI_BIAS_GELU>(g, s, stamps);
+        case EPI_BIAS_RES: return launch256s<EPI_BIAS_RES>(g, s, stamps);
+        case EPI_PATCH: return launch256s<EPI_PATCH>(g, s, stamps);
+        case EPI_F32: return launch256s<EPI_F32>(g, s, stamps);
         default: return hipErrorInvalidValue;
     }
 }

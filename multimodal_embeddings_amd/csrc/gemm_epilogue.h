@@ -70,3 +70,36 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, const EpiRow
     for (int r = 0; r < 4; ++r) ov[r] = (bf16_t)v[r];
     *(bf16x4*)o = ov;
 }
+
+// ---- 16-byte epilogue accesses (halves the number of store / load instructions) -------------
+// The epilogue of a 256x256 tile is store-ISSUE bound (one CU retires a vector store
+// instruction every few tens of cycles whatever its width), so width is what counts.  A lane
+// owns 4 consecutive columns (8 bytes of bf16) of a 16x16 accumulator tile; lanes fq and fq^1
+// (16 lanes apart) own the neighbouring 4.  v_permlane16_swap exchanges the odd 16-lane rows of
+// one register with the even rows of another: applied to the packed data of two adjacent
+// column tiles (j, j+1) it leaves every lane with 8 consecutive columns of ONE tile:
+//   fq even -> tile j,   columns 8*(fq>>1) .. +7      fq odd -> tile j+1, same columns
+// The same swap applied to 16 bytes loaded in that layout returns them to accumulator layout.
+__device__ __forceinline__ uint4 pair_to_row16(uint2 p, uint2 q) {
+    const auto a = __builtin_amdgcn_permlane16_swap(p.x, q.x, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(p.y, q.y, false, false);
+    return make_uint4(a[0], b[0], a[1], b[1]);
+}
+__device__ __forceinline__ void row16_to_pair(uint4 x, uint2& p, uint2& q) {
+    const auto a = __builtin_amdgcn_permlane16_swap(x.x, x.z, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(x.y, x.w, false, false);
+    p = make_uint2(a[0], b[0]);
+    q = make_uint2(a[1], b[1]);
+}
+__device__ __forceinline__ uint2 pack_bf16x4(f32x4 v) {
+    bf16x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+    return __builtin_bit_cast(uint2, o);
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
+    const bf16x4 b = __builtin_bit_cast(bf16x4, u);
+    return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+}
+// column (within the wave's 64) of this lane's 16-byte piece for the tile pair (jp, jp+1)
+__device__ __forceinline__ int row16_col(int jp, int fq) { return ((fq & 1) ? (jp + 1) * 16 : jp * 16) + (fq >> 1) * 8; }

@@ -26,7 +26,7 @@ struct GemmArgs {
     int64_t ldf;
 };
 
-hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0);
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0, unsigned long long* stamps = nullptr);
 
 // LayerNorm over rows of 768 bf16 (f32 statistics), bf16 out.
 hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s);
