@@ -64,6 +64,29 @@ def same_prefix_mask(names, prefix_length: int = 20) -> np.ndarray:
     return m
 
 
+def pair_terms(emb, area_percentage, regions_i, rows_j, n_valid_j, *, metric="cosine", effective_threshold=0.1,
+               max_query_regions=10, top_k=10, sim=None):
+    """Weighted terms of ONE page pair (wrc:199-226): the list whose np.sum is S[i,j] before normalisation."""
+    weighted = []
+    n_results = min(top_k, n_valid_j)  # :210
+    for r in regions_i[:max_query_regions]:  # :199
+        area_i = area_percentage[r] / 100.0
+        if area_i == 0:
+            continue
+        if sim is None:
+            d = distances(emb[r], emb[rows_j], metric)
+        else:
+            c64 = np.asarray(sim[r, rows_j], dtype=np.float64)
+            d = 1.0 - c64 if metric == "cosine" else 2.0 - 2.0 * c64
+        order = np.argsort(d, kind="stable")[:n_results]
+        for k in order:
+            dist = float(d[k])
+            area_j = area_percentage[rows_j[k]] / 100.0
+            if dist <= (1.0 - effective_threshold) and area_j > 0:  # :223
+                weighted.append((1.0 - dist) * area_i * area_j)
+    return weighted
+
+
 def compute_image_similarity_matrix(
     emb: np.ndarray,
     area_percentage: np.ndarray,
@@ -114,23 +137,8 @@ def compute_image_similarity_matrix(
             if skip_same_prefix:
                 if names[i][: min(prefix_length, len(names[i]))] == names[j][: min(prefix_length, len(names[j]))]:
                     continue
-            weighted = []
-            cand = rows_of[j]
-            n_results = min(top_k, len(rj))  # :210
-            for r in ri[:max_query_regions]:  # :199
-                if area[r] == 0:
-                    continue
-                if sim is None:
-                    d = distances(emb[r], emb[cand], metric)
-                else:
-                    c64 = np.asarray(sim[r, cand], dtype=np.float64)
-                    d = 1.0 - c64 if metric == "cosine" else 2.0 - 2.0 * c64
-                order = np.argsort(d, kind="stable")[:n_results]
-                for k in order:
-                    dist = float(d[k])
-                    area_j = area_percentage[cand[k]] / 100.0
-                    if dist <= (1.0 - effective_threshold) and area_j > 0:  # :223
-                        weighted.append((1.0 - dist) * area[r] * area_j)
+            weighted = pair_terms(emb, area_percentage, ri, rows_of[j], len(rj), metric=metric, effective_threshold=effective_threshold,
+                                  max_query_regions=max_query_regions, top_k=top_k, sim=sim)
             if weighted:
                 s = np.sum(weighted)
                 S[i, j] = s

@@ -1,0 +1,181 @@
+"""End-to-end GPU tests through the reference-shaped API (BASELINE.json configs C1, C3, C5) and
+size-independent properties at the BASELINE sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def embedder():
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+
+    return RegionEmbedder()
+
+
+def _manifest(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "crops_manifest.json")))
+
+
+def test_c1_sixteen_crops_of_one_page_through_reference_api(embedder, golden_dir):
+    """C1: 16 bbox crops of one bundled page -> 16 x 768 vectors + 16 x 16 cosine, list/None contract."""
+    from PIL import Image
+
+    from multimodal_embeddings_amd.cross_compare import cross_compare
+    from oracle import preprocess as opre
+    from oracle import vit as ovit
+
+    man = _manifest(golden_dir)
+    paths = [os.path.join(golden_dir, "crops", c["file"]) for c in man["crops"][: man["c1_count"]]]
+    assert len(paths) == 16
+    holes = paths[:5] + ["/nonexistent/region.png"] + paths[5:]
+    out = embedder.get_image_embeddings(holes)
+    assert len(out) == 17 and out[5] is None  # order preserved, failed item is a None hole (embedder.py:135-137)
+    vecs = [v for v in out if v is not None]
+    assert all(isinstance(v, list) and len(v) == 768 and isinstance(v[0], float) for v in vecs)
+    arrays = [np.array(Image.open(p).convert("RGB")) for p in paths]
+    want = ovit.vit_embed(np.stack([opre.preprocess_to_patches(a) for a in arrays]), make_vit_weights(seed=1))
+    got = np.array(vecs, dtype=np.float64)
+    assert np.max(1.0 - np.sum(got * want, axis=1)) <= 1e-3
+    sim = cross_compare(vecs, engine=embedder.engine)
+    assert sim.shape == (16, 16) and np.abs(sim - want @ want.T).max() < 2e-2 and np.allclose(np.diag(sim), 1.0, atol=1e-2)
+    # embed(region) for a path, a PIL image and an array give the same vector
+    v0 = embedder.embed(paths[0])
+    assert np.array_equal(v0, embedder.embed(Image.open(paths[0])))
+    assert np.array_equal(v0, embedder.embed(arrays[0]))
+    assert np.array_equal(v0, np.asarray(vecs[0], dtype=np.float32))
+    assert embedder.get_image_embeddings([]) == []
+    assert embedder.get_image_embeddings(["/nonexistent/x.png"], is_query=True) == [None]
+
+
+def test_c5_end_to_end_embed_compare_cluster_matches_oracle(embedder, golden_dir):
+    """Real + synthetic crops -> GPU embeddings -> collection -> page matrix -> clusters; every
+    stage checked against the oracle on the same inputs, labels exactly."""
+    from PIL import Image
+
+    from multimodal_embeddings_amd.weighted_region_clustering import (
+        RegionCollection,
+        cluster_images,
+        compute_image_similarity_matrix,
+    )
+    from oracle import cluster as oc
+    from oracle import compare as ocmp
+
+    man = _manifest(golden_dir)
+    real = [np.array(Image.open(os.path.join(golden_dir, "crops", c["file"])).convert("RGB")) for c in man["crops"]]
+    rng = np.random.default_rng(3)
+    P, per = 12, 14
+    crops = []
+    for i in range(P * per):
+        base = real[(i * 7) % len(real)]
+        h, w = base.shape[:2]
+        y0, x0 = int(rng.integers(0, max(1, h // 3))), int(rng.integers(0, max(1, w // 3)))
+        crops.append(np.ascontiguousarray(base[y0 : max(y0 + 8, h - int(rng.integers(0, h // 4 + 1))), x0 : max(x0 + 8, w - int(rng.integers(0, w // 4 + 1)))]))
+    vecs = embedder.get_image_embeddings(crops)
+    assert all(v is not None for v in vecs)
+    names = [f"Synthetic newspaper number {p:02d} page.png" for p in range(P)]
+    names[4] = names[3][:20] + " second scan.png"  # same 20-char prefix as page 3 -> skipped pair
+    col = RegionCollection()
+    area = np.exp(rng.uniform(np.log(0.05), np.log(15.0), P * per))
+    area[5] = 0.0
+    ids, metas = [], []
+    for i in range(P * per):
+        ids.append(f"region_{i}")
+        metas.append({"parent_image_name": names[i // per], "region_type": "plain_text" if i % 17 else "abandon",
+                      "area_percentage": float(area[i]), "is_region": True})
+    col.upsert(ids=ids, embeddings=vecs, metadatas=metas)
+    S, nm = compute_image_similarity_matrix(col, ["/data/" + n for n in names], engine=embedder.engine)
+    assert nm == names and S.shape == (P, P) and S[3, 4] == 0 and np.array_equal(np.diag(S), np.ones(P))
+    # oracle on the kernel's own cosine values (decision-for-decision), same table
+    e16 = embedder.engine.normalise_rows(torch.tensor(vecs, dtype=torch.float32, device="cuda"))
+    sims = embedder.engine.cosine(e16, e16).cpu().numpy()
+    types = [m["region_type"] for m in metas]
+    S_want, _ = ocmp.compute_image_similarity_matrix(None, area, np.repeat(np.arange(P), per), names, types, sim=sims)
+    assert np.abs(S - S_want).max() <= 1e-12
+    res = cluster_images(S.copy(), names, engine=embedder.engine)
+    want = oc.cluster_images(S.copy(), names)
+    assert res["labels"] == want["labels"] and res["n_clusters"] == want["n_clusters"]
+    assert res["clusters"] == want["clusters"]
+    for k, v in want["cluster_cohesion"].items():
+        assert res["cluster_cohesion"][k] == pytest.approx(v, abs=1e-15)
+
+
+def test_c2_properties_at_full_size(embedder):
+    """4096 synthetic 224x224 crops: unit norms, run-to-run determinism, cosine symmetry."""
+    n = 4096
+    crops = torch.from_numpy(synthetic_crops(n, seed=0)).cuda()
+    a32, a16 = embedder.embed_uniform(crops)
+    b32, b16 = embedder.embed_uniform(crops)
+    torch.cuda.synchronize()
+    assert torch.equal(a32, b32) and torch.equal(a16, b16)
+    assert torch.isfinite(a32).all()
+    assert torch.allclose(a32.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    sim = embedder.engine.cosine(a16, a16)
+    assert torch.equal(sim, sim.T)
+    assert (sim.diagonal() - 1).abs().max() < 1e-2 and sim.max() <= 1.02
+    # a sample of rows against the oracle (full-size run, sampled check)
+    from oracle import preprocess as opre
+    from oracle import vit as ovit
+
+    idx = [0, 1, 1023, 1024, 2047, 4095]
+    host = crops[idx].cpu().numpy()
+    want = ovit.vit_embed(np.stack([opre.preprocess_to_patches(c) for c in host]), make_vit_weights(seed=1))
+    assert np.max(1.0 - np.sum(a32[idx].cpu().numpy() * want, axis=1)) <= 1e-3
+
+
+def test_c5_page_matrix_properties_at_full_size(embedder):
+    """65536 regions in 512 pages of 128 (SURVEY.md §8d C5 structure): structural properties of S
+    plus sampled page pairs against the oracle's pair rule."""
+    from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+    from oracle import compare as ocmp
+
+    eng = embedder.engine
+    P, per, d = 512, 128, 768
+    N = P * per
+    g = torch.Generator(device="cuda").manual_seed(5)
+    centres = torch.randn(40, d, generator=g, device="cuda") * 1.5
+    lab = torch.randint(0, 40, (N,), generator=g, device="cuda")
+    e16 = eng.normalise_rows(torch.randn(N, d, generator=g, device="cuda") + centres[lab])
+    rng = np.random.default_rng(8)
+    area = np.exp(rng.uniform(np.log(1e-2), np.log(20.0), N))
+    area[rng.random(N) < 0.01] = 0.0
+    valid = (area > 0).astype(np.uint8)
+    offs = (np.arange(P + 1) * per).astype(np.int32)
+    names = [f"{p:04d} synthetic page of the full-size set.png" for p in range(P)]
+    for p in range(0, 32, 2):  # 16 duplicated prefixes
+        names[p + 1] = names[p][:20] + " dup.png"
+    S = page_similarity_from_table(e16, area, valid, offs, names, engine=eng)
+    torch.cuda.synchronize()
+    S = S.cpu().numpy()
+    assert S.shape == (P, P) and np.array_equal(S, S.T) and np.array_equal(np.diag(S), np.ones(P))
+    off = S[~np.eye(P, dtype=bool)]
+    assert off.max() == 1.0 and off.min() >= 0.0 and np.isfinite(S).all()
+    assert all(S[p, p + 1] == 0 for p in range(0, 32, 2))
+    # sampled pairs: oracle pair rule on the kernel's own cosine values for the query rows
+    Sraw = page_similarity_from_table(e16, area, valid, offs, names, normalise=False, engine=eng).cpu().numpy()
+    pairs = [(int(a), int(b)) for a, b in rng.integers(0, P, (40, 2)) if a != b]
+    for i, j in pairs:
+        i, j = min(i, j), max(i, j)
+        if names[i][:20] == names[j][:20]:
+            continue
+        rows_i = np.arange(i * per, (i + 1) * per)
+        rows_j = np.arange(j * per, (j + 1) * per)
+        reg_i = rows_i[valid[rows_i] > 0]
+        q = reg_i[:10]
+        sims = eng.cosine(e16[q.tolist()], e16[rows_j.tolist()]).cpu().numpy()
+        simmap = {int(r): sims[k] for k, r in enumerate(q)}
+
+        class _Sim:
+            def __getitem__(self, key):
+                r, cand = key
+                return simmap[int(r)][np.asarray(cand) - j * per]
+
+        terms = ocmp.pair_terms(None, area, reg_i, rows_j, int(valid[rows_j].sum()), sim=_Sim())
+        want = float(np.sum(terms)) if terms else 0.0
+        assert Sraw[i, j] == pytest.approx(want, rel=1e-13, abs=1e-18), (i, j)
