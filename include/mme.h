@@ -81,7 +81,8 @@ int mme_load_vit(mme_ctx* ctx, const mme_vit_weights* w);
  * Replaces the `image_mean` / `image_std` of the checkpoint's preprocessor_config. */
 int mme_set_normalisation(mme_ctx* ctx, const float mean[3], const float std[3]);
 
-/* Rows of the internal activation workspace = crops per encoder pass (default 1024). */
+/* Rows of the internal activation workspace = crops per encoder pass (default 4096: one pass
+ * for the headline batch; 11.6 GB of workspace; larger passes lose less to tile quantisation). */
 int mme_set_chunk(mme_ctx* ctx, int crops_per_pass);
 
 /* Tuning / test knob: which MFMA GEMM tiling serves K2/K4/K6/K7/K9.  0 = by shape (default),

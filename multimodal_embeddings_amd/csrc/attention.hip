@@ -1,133 +1,193 @@
 // K5: fused multi-head self-attention for ViT-B/16 (T = 197 tokens, 12 heads, dh = 64).
 //
 // Restates transformers models/vit/modeling_vit.py:164-189 (softmax(Q K^T / 8) V, softmax in
-// f32) for one (crop, head) per workgroup.  T is short, so there is no online softmax: the
-// whole 32 x 224 score strip of a query block lives in accumulator registers.
+// f32).  T is short, so there is no online softmax: the whole 32 x 224 score strip of a query
+// block lives in accumulator registers.
 //
-//   * K and V of the head are staged once in LDS (2 x 28 KiB, keys padded 197 -> 224).
-//   * S^T = K . Q^T with mfma_f32_32x32x16_bf16: the accumulator then has the QUERY on the
-//     lane and the 32 keys of a tile in its 16 registers (x2 lane halves), so the softmax
-//     max / sum are in-lane reductions plus one cross-half shuffle, and ...
-//   * ... the normalised P tile is already the B operand of O^T = V^T . P^T (guide §3,
-//     "an accumulator tile as the next MFMA's operand": registers 8s..8s+7 -> k-step s).
-//   * V^T fragments come from the row-major V image through ds_read_b64_tr_b16 (hardware
-//     transposed LDS read), so V is never transposed in memory.
-//   * O^T leaves 4 consecutive head-dims per lane -> 8-byte stores into out[token, h*64+d].
+// One 8-wave workgroup walks the 12 heads of ONE crop:
+//   * K and V of head h+1 stream into the second LDS buffer by LDS-DMA (global_load_lds, no VGPR
+//     round trip) while head h is computed, and the Q fragments of head h+1 are prefetched into
+//     registers: after the first head no memory latency is exposed.  One barrier per head.
+//   * waves 0..6 own the 7 query blocks of 32 (197 -> 224); wave 7 only feeds DMA.
+//   * S^T = K . Q^T with mfma_f32_32x32x16_bf16: the accumulator has the QUERY on the lane and
+//     the 32 keys of a tile in its 16 registers (x2 lane halves), so softmax max / sum are in-lane
+//     reductions plus one cross-half shuffle, and the exponentiated tile is already the B operand
+//     of O^T = V^T . P^T (guide §3, "an accumulator tile as the next MFMA's operand").
+//     Normalisation by 1/sum is deferred to the 32 output values per lane.
+//   * V^T fragments come from the row-major V image through ds_read_b64_tr_b16.  LDS images:
+//     K rows of 128 B with chunk ^= (row>>1)&7 (conflict-free ds_read_b128), V rows of 128 B with
+//     the two 64-byte halves swapped when bit 1 of the row is set (conflict-free transposed
+//     reads); both swizzles are applied to the DMA source address.
+//   * O^T leaves 4 consecutive head-dims per lane; v_permlane32_swap pairs the two lane halves
+//     into 16-byte stores.
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int TPAD = 224;            // 7 key tiles of 32
-constexpr int ROWB = VIT_DH * 2;     // 128-byte K/V rows in LDS
+constexpr int TPAD = 224;              // 7 key tiles of 32
+constexpr int ROWB = VIT_DH * 2;       // 128-byte K/V rows in LDS
 constexpr int QKV_LD = 3 * VIT_D * 2;  // 4608-byte rows of the fused QKV activation
+constexpr int KV_BYTES = TPAD * ROWB;  // 28 KiB
+constexpr int BUF_BYTES = 2 * KV_BYTES;
+constexpr int NPIECE = 25;             // 25 x 8 rows = 200 >= 197
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * TPAD * ROWB];
-    char* Kl = lds;
-    char* Vl = lds + TPAD * ROWB;
+#define S_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x (K | V)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.x;
-    const int b = bh / VIT_H, h = bh - b * VIT_H;
-    const char* base = (const char*)qkv + (size_t)b * VIT_T * QKV_LD + h * ROWB;
+    const int b = blockIdx.x;
+    const char* base = (const char*)qkv + (size_t)b * VIT_T * QKV_LD;
 
-    // stage K (chunk-swizzled for conflict-free ds_read_b128) and V (row-major for tr reads)
-    for (int idx = tid; idx < TPAD * 8; idx += 256) {
-        const int t = idx >> 3, c = idx & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (t < VIT_T) {
-            const char* row = base + (size_t)t * QKV_LD + c * 16;
-            kv = *(const uint4*)(row + VIT_D * 2);
-            vv = *(const uint4*)(row + 2 * VIT_D * 2);
-        }
-        *(uint4*)(Kl + t * ROWB + ((c ^ ((t >> 1) & 7)) << 4)) = kv;
-        *(uint4*)(Vl + t * ROWB + (c << 4)) = vv;
+    // V rows 200..223 are never written by DMA: zero them once in both buffers (P is 0 there, but
+    // 0 * garbage could be NaN).  Rows 197..199 receive clamped copies of row 196 (finite).
+    for (int i = tid; i < 2 * 24 * 8; i += 512) {
+        const int buf = i / (24 * 8), r = (i >> 3) % 24, c = i & 7;
+        *(uint4*)(lds + buf * BUF_BYTES + KV_BYTES + (200 + r) * ROWB + c * 16) = make_uint4(0, 0, 0, 0);
     }
-    __syncthreads();
+
+    // DMA of one head: 25 K pieces + 25 V pieces (8 rows x 128 B each) over 8 waves
+    auto dma_head = [&](int h, int buf) {
+        const char* hb = base + h * ROWB;
+        char* kdst = lds + buf * BUF_BYTES;
+        for (int p = wave; p < 2 * NPIECE; p += 8) {
+            const bool isv = p >= NPIECE;
+            const int pp = isv ? p - NPIECE : p;
+            const int row = pp * 8 + (lane >> 3);
+            const int slot = lane & 7;
+            const int chunk = isv ? (slot ^ (((row >> 1) & 1) << 2)) : (slot ^ ((row >> 1) & 7));
+            const char* src = hb + (size_t)min(row, VIT_T - 1) * QKV_LD + (isv ? 2 : 1) * VIT_D * 2 + chunk * 16;
+            glds16(src, kdst + (isv ? KV_BYTES : 0) + pp * 1024);
+        }
+    };
 
     const int r = lane & 31, hh = lane >> 5;
     const int ksw = (r >> 1) & 7;
     // transposed-read lane roles: group g of 16 lanes, lane 4q+p supplies row q, cols 4p..4p+3
     const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
-    const int v_lane_off = (4 * (g >> 1) + tq) * ROWB + (16 * (g & 1) + 4 * tp) * 2;
+    const int vflag = (tq >> 1) & 1;  // bit 1 of the row this lane addresses: selects the swapped half
+    const int v_row_off = (4 * (g >> 1) + tq) * ROWB + (16 * (g & 1) + 4 * tp) * 2;
+    const int v_off0 = v_row_off + ((0 ^ vflag) << 6), v_off1 = v_row_off + ((1 ^ vflag) << 6);
     const float sc = 0.125f * 1.44269504088896341f;  // dh^-0.5 * log2(e)
+    const int q = wave * 32 + r;                      // this lane's query (waves 0..6)
+    const bool active = wave < 7;
+    const char* qp = base + (size_t)min(q, VIT_T - 1) * QKV_LD + hh * 16;
 
-    for (int qb = wave; qb < 7; qb += 4) {
-        const int q = qb * 32 + r;
-        const char* qp = base + (size_t)min(q, VIT_T - 1) * QKV_LD + hh * 16;
-        bf16x8 qf[4];
+    bf16x8 qf[4], qn[4];
+    dma_head(0, 0);
+    if (active) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+    }
 
-        f32x16 s[7];
-#pragma unroll
-        for (int kt = 0; kt < 7; ++kt) {
-            f32x16 a;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) a[e] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(Kl + (kt * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
-                a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
-            }
-            s[kt] = a;
+    for (int h = 0; h < VIT_H; ++h) {
+        const int buf = h & 1;
+        const char* Kl = lds + buf * BUF_BYTES;
+        const char* Vl = Kl + KV_BYTES;
+        // head h has landed (each wave waits for its own pieces), everybody is done with head h-1
+        // (the 4 output stores of head h-1 are this wave's youngest vector-memory operations and may
+        // stay in flight: vmcnt retires in order and counts stores)
+        if (h == 0 || !active) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         }
-        // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding
-        float mx = -INFINITY;
+        S_BARRIER();
+        if (h + 1 < VIT_H) {
+            dma_head(h + 1, buf ^ 1);
+            if (active) {
 #pragma unroll
-        for (int kt = 0; kt < 7; ++kt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool valid = (kt < 6) || ((e >> 2) == 0 && (e & 3) + 4 * hh < VIT_T - 192);
-                if (valid) mx = fmaxf(mx, s[kt][e]);
+                for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qp + (h + 1) * ROWB + ks * 32);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mxs = mx * sc;
-        float sum = 0.f;
+        }
+        if (active) {
+            f32x16 s[7];
 #pragma unroll
-        for (int kt = 0; kt < 7; ++kt)
+            for (int kt = 0; kt < 7; ++kt) {
+                f32x16 a;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const bool valid = (kt < 6) || ((e >> 2) == 0 && (e & 3) + 4 * hh < VIT_T - 192);
-                const float p = valid ? exp2f(s[kt][e] * sc - mxs) : 0.f;
-                s[kt][e] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
-
-        f32x16 o[2];
+                for (int e = 0; e < 16; ++e) a[e] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 7; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)(s[kt][8 * s2 + j] * inv);
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char* va = Vl + (kt * 32 + s2 * 16) * ROWB + db * 64 + v_lane_off;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * ROWB));
-                    const s16x8 vc = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), pf, o[db], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(Kl + (kt * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
                 }
+                s[kt] = a;
             }
-        if (q < VIT_T) {
-            bf16_t* op = out + ((size_t)b * VIT_T + q) * VIT_D + h * VIT_DH;
+            // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool valid = (kt < 6) || ((e >> 2) == 0 && (e & 3) + 4 * hh < VIT_T - 192);
+                    if (valid) mx = fmaxf(mx, s[kt][e]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mxs = mx * sc;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const bool valid = (kt < 6) || ((e >> 2) == 0 && (e & 3) + 4 * hh < VIT_T - 192);
+                    const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s[kt][e], sc, -mxs)) : 0.f;
+                    s[kt][e] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+
+            f32x16 o[2];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * s2 + j];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const char* va = Vl + (kt * 32 + s2 * 16) * ROWB + (db ? v_off1 : v_off0);
+                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
+                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * ROWB));
+                        const s16x8 vc = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), pf, o[db], 0, 0, 0);
+                    }
+                }
+            if (h + 1 < VIT_H) {  // before the stores: the wait for the prefetched Q must not cover them
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
+            }
+            // o[db][4*rg + j] = O[q][32db + 8rg + 4hh + j]: pair the lane halves into 16-byte stores
+            bf16_t* op = out + ((size_t)b * VIT_T + min(q, VIT_T - 1)) * VIT_D + h * VIT_DH;
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    bf16x4 ov;
+                for (int rp = 0; rp < 4; rp += 2) {
+                    uint2 u0, u1;  // row groups rp and rp+1 of this lane
+                    {
+                        bf16x4 t0, t1;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)o[db][rg * 4 + j];
-                    *(bf16x4*)(op + db * 32 + rg * 8 + hh * 4) = ov;
+                        for (int j = 0; j < 4; ++j) {
+                            t0[j] = (bf16_t)(o[db][rp * 4 + j] * inv);
+                            t1[j] = (bf16_t)(o[db][(rp + 1) * 4 + j] * inv);
+                        }
+                        u0 = __builtin_bit_cast(uint2, t0);
+                        u1 = __builtin_bit_cast(uint2, t1);
+                    }
+                    // lower half keeps group rp and receives the upper half's group rp (dims +4..+7);
+                    // upper half keeps group rp+1 and receives the lower half's (dims +0..+3)
+                    const auto ax = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
+                    const auto ay = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
+                    const uint4 w = make_uint4(ax[0], ay[0], ax[1], ay[1]);
+                    if (q < VIT_T) *(uint4*)(op + db * 32 + (rp + hh) * 8) = w;
                 }
         }
     }
@@ -137,6 +197,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_t197(const bf16_t* __restrict
 
 hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(attn_fwd_t197, dim3(B * VIT_H), dim3(256), 0, s, (const bf16_t*)qkv, (bf16_t*)out, B);
+    static bool attr_set = false;
+    const int smem = 2 * BUF_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_t197, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_fwd_t197, dim3(B), dim3(512), smem, s, (const bf16_t*)qkv, (bf16_t*)out, B);
     return hipGetLastError();
 }

@@ -43,7 +43,7 @@ struct mme_ctx {
     std::string err;
     bool loaded = false;
     float ln_eps = 1e-12f;
-    int chunk = 1024;
+    int chunk = 4096;
     int gemm_variant = 0;
     // weights
     std::vector<void*> allocs;
