@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--crops", type=int, default=CROPS_PER_GPU, help="crops per GPU (headline config: 4096)")
     ap.add_argument("--chunk", type=int, default=0, help="crops per encoder pass (0 = library default)")
     ap.add_argument("--gemm-variant", type=int, default=0, help="0 auto, 1 128x128, 2 256 ping-pong, 3 256 streaming")
+    ap.add_argument("--no-ln-fusion", action="store_true", help="separate LayerNorm kernel instead of folding it into the GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,6 +100,8 @@ def main():
         eng.set_chunk(args.chunk)
     if args.gemm_variant:
         eng.set_gemm_variant(args.gemm_variant)
+    if args.no_ln_fusion:
+        eng.set_ln_fusion(False)
 
     n = args.crops
     start = rank * n

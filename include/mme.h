@@ -90,6 +90,11 @@ int mme_set_chunk(mme_ctx* ctx, int crops_per_pass);
  * (same MFMA instruction, same K order per output element). */
 int mme_set_gemm_variant(mme_ctx* ctx, int variant);
 
+/* LayerNorm folding (default on): LN1 / LN2 are folded into the QKV / fc1 GEMMs
+ * (W' = W*gamma, out = rstd*(W'x - mean*colsum) + b'), so the residual stream is read once per
+ * LayerNorm and no normalised copy is written.  0 = separate LayerNorm kernel (A/B, tests). */
+int mme_set_ln_fusion(mme_ctx* ctx, int on);
+
 /* ---- K1: crop -> resize -> pad -> normalise -> patchify ------------------------------
  * Replaces, per crop, `processor(images=[image])` (embedder.py:117-121; transformers
  * image_processing_pil_mllama.py:483-541 with tile 224, one tile): aspect-preserving

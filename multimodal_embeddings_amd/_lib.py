@@ -48,6 +48,7 @@ EXPORTS = {
     "mme_set_normalisation": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mme_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_set_ln_fusion": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -169,6 +170,9 @@ class Engine:
 
     def set_gemm_variant(self, variant: int):
         self._check(self.lib.mme_set_gemm_variant(self.h, int(variant)), "mme_set_gemm_variant")
+
+    def set_ln_fusion(self, on: bool):
+        self._check(self.lib.mme_set_ln_fusion(self.h, int(bool(on))), "mme_set_ln_fusion")
 
     def set_chunk(self, crops: int):
         self._check(self.lib.mme_set_chunk(self.h, int(crops)), "mme_set_chunk")

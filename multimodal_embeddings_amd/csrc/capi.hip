@@ -27,6 +27,9 @@ struct LayerDev {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     bf16_t *qkv_w, *o_w, *fc1_w, *fc2_w;
     float *qkv_b, *o_b, *fc1_b, *fc2_b;
+    // LayerNorm folded into the consuming GEMM: W' = bf16(W * gamma), colsum = sum_k W', b' = b + W . beta
+    bf16_t *qkv_wf, *fc1_wf;
+    float *qkv_cs, *qkv_bf, *fc1_cs, *fc1_bf;
 };
 
 enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7 };
@@ -45,6 +48,7 @@ struct mme_ctx {
     float ln_eps = 1e-12f;
     int chunk = 4096;
     int gemm_variant = 0;
+    bool fuse_ln = true;
     // weights
     std::vector<void*> allocs;
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
@@ -53,7 +57,7 @@ struct mme_ctx {
     float* lut = nullptr;  // [3,256]
     // workspace (sized for `chunk` crops)
     int ws_chunk = 0;
-    DevBuf x, hbuf, qkv, att, mlp, patches, tmp, crops, hwork, page_ws, cluster_ws;
+    DevBuf x, hbuf, qkv, att, mlp, stats, patches, tmp, crops, hwork, page_ws, cluster_ws;
     // host staging for crop tables
     std::vector<CropDesc> h_crops;
     std::vector<HWork> h_work;
@@ -133,6 +137,43 @@ int upload_bf16(mme_ctx* c, const float* const* srcs, const size_t* rows, int ns
     return MME_OK;
 }
 
+// LayerNorm folding for `y = W . LN(x) + b`:  W'[n,k] = bf16(W[n,k] * gamma[k]),
+// colsum[n] = sum_k W'[n,k] (of the ROUNDED values, so that r*(W'x - mu*colsum) is exact algebra),
+// b'[n] = b[n] + sum_k W[n,k] * beta[k].  Sums in f64 on the host.
+int upload_folded(mme_ctx* c, const float* const* ws, const float* const* bs, const size_t* rows, int nsrc, size_t cols,
+                  const float* gamma, const float* beta, bf16_t** wf, float** cs, float** bf) {
+    size_t total = 0;
+    for (int i = 0; i < nsrc; ++i) total += rows[i];
+    std::vector<uint16_t> hw(total * cols);
+    std::vector<float> hcs(total), hbf(total);
+    size_t o = 0;
+    for (int i = 0; i < nsrc; ++i)
+        for (size_t n = 0; n < rows[i]; ++n, ++o) {
+            double s = 0.0, t = 0.0;
+            for (size_t k = 0; k < cols; ++k) {
+                const float w = ws[i][n * cols + k];
+                const uint16_t q = f32_to_bf16_rne(w * gamma[k]);
+                hw[o * cols + k] = q;
+                uint32_t u = (uint32_t)q << 16;
+                float wq;
+                memcpy(&wq, &u, 4);
+                s += (double)wq;
+                t += (double)w * (double)beta[k];
+            }
+            hcs[o] = (float)s;
+            hbf[o] = (float)((double)bs[i][n] + t);
+        }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, hw.size() * 2);
+    if (e != hipSuccess) return fail(c, MME_E_NOMEM, "hipMalloc weights: %s", hipGetErrorString(e));
+    c->allocs.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    *wf = (bf16_t*)p;
+    int r;
+    if ((r = upload_f32(c, hcs.data(), hcs.size(), cs))) return r;
+    return upload_f32(c, hbf.data(), hbf.size(), bf);
+}
+
 int upload_f32_cat(mme_ctx* c, const float* const* srcs, const size_t* n, int nsrc, float** dst) {
     std::vector<float> h;
     for (int i = 0; i < nsrc; ++i) h.insert(h.end(), srcs[i], srcs[i] + n[i]);
@@ -148,6 +189,7 @@ int ensure_workspace(mme_ctx* c) {
     if ((r = ensure(c, c->qkv, rows * 3 * VIT_D * 2))) return r;
     if ((r = ensure(c, c->att, rows * VIT_D * 2))) return r;
     if ((r = ensure(c, c->mlp, rows * VIT_F * 2))) return r;
+    if ((r = ensure(c, c->stats, rows * 2 * sizeof(float)))) return r;
     c->ws_chunk = c->chunk;
     return MME_OK;
 }
@@ -211,11 +253,21 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
     }
     for (int l = 0; l < VIT_L; ++l) {
         const LayerDev& L = c->layer[l];
-        {
-            Timed t(c, s, KC_LN);
-            HIP_TRY(c, launch_layernorm(c->x.p, L.ln1_g, L.ln1_b, c->hbuf.p, M, c->ln_eps, s));
-        }
-        {
+        if (c->fuse_ln) {  // LN1 folded into the QKV GEMM: x is read once, nothing normalised is written
+            {
+                Timed t(c, s, KC_LN);
+                HIP_TRY(c, launch_ln_stats(c->x.p, M, c->ln_eps, (float*)c->stats.p, s));
+            }
+            Timed t(c, s, KC_GEMM);
+            g = GemmArgs{};
+            g.A = c->x.p; g.W = L.qkv_wf; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
+            g.bias = L.qkv_bf; g.colsum = L.qkv_cs; g.ln_stats = (const float*)c->stats.p; g.out = c->qkv.p; g.ldo = 3 * VIT_D;
+            HIP_TRY(c, launch_gemm(EPI_LN_BIAS, g, s, c->gemm_variant));
+        } else {
+            {
+                Timed t(c, s, KC_LN);
+                HIP_TRY(c, launch_layernorm(c->x.p, L.ln1_g, L.ln1_b, c->hbuf.p, M, c->ln_eps, s));
+            }
             Timed t(c, s, KC_GEMM);
             g = GemmArgs{};
             g.A = c->hbuf.p; g.W = L.qkv_w; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
@@ -233,11 +285,21 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g.bias = L.o_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
             HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
         }
-        {
-            Timed t(c, s, KC_LN);
-            HIP_TRY(c, launch_layernorm(c->x.p, L.ln2_g, L.ln2_b, c->hbuf.p, M, c->ln_eps, s));
-        }
-        {
+        if (c->fuse_ln) {
+            {
+                Timed t(c, s, KC_LN);
+                HIP_TRY(c, launch_ln_stats(c->x.p, M, c->ln_eps, (float*)c->stats.p, s));
+            }
+            Timed t(c, s, KC_GEMM);
+            g = GemmArgs{};
+            g.A = c->x.p; g.W = L.fc1_wf; g.M = M; g.N = VIT_F; g.K = VIT_D;
+            g.bias = L.fc1_bf; g.colsum = L.fc1_cs; g.ln_stats = (const float*)c->stats.p; g.out = c->mlp.p; g.ldo = VIT_F;
+            HIP_TRY(c, launch_gemm(EPI_LN_BIAS_GELU, g, s, c->gemm_variant));
+        } else {
+            {
+                Timed t(c, s, KC_LN);
+                HIP_TRY(c, launch_layernorm(c->x.p, L.ln2_g, L.ln2_b, c->hbuf.p, M, c->ln_eps, s));
+            }
             Timed t(c, s, KC_GEMM);
             g = GemmArgs{};
             g.A = c->hbuf.p; g.W = L.fc1_w; g.M = M; g.N = VIT_F; g.K = VIT_D;
@@ -351,7 +413,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -401,6 +463,7 @@ int mme_load_vit(mme_ctx* c, const mme_vit_weights* w) {
         if ((r = upload_bf16(c, qkv, r3, 3, VIT_D, &L.qkv_w))) return r;
         const float* qkvb[3] = {a.q_b, a.k_b, a.v_b};
         if ((r = upload_f32_cat(c, qkvb, r3, 3, &L.qkv_b))) return r;
+        if ((r = upload_folded(c, qkv, qkvb, r3, 3, VIT_D, a.ln1_g, a.ln1_b, &L.qkv_wf, &L.qkv_cs, &L.qkv_bf))) return r;
         const float* o[1] = {a.o_w};
         const size_t r1[1] = {VIT_D};
         if ((r = upload_bf16(c, o, r1, 1, VIT_D, &L.o_w))) return r;
@@ -409,6 +472,10 @@ int mme_load_vit(mme_ctx* c, const mme_vit_weights* w) {
         const size_t rf1[1] = {VIT_F};
         if ((r = upload_bf16(c, f1, rf1, 1, VIT_D, &L.fc1_w))) return r;
         if ((r = upload_f32(c, a.fc1_b, VIT_F, &L.fc1_b))) return r;
+        {
+            const float* f1b[1] = {a.fc1_b};
+            if ((r = upload_folded(c, f1, f1b, rf1, 1, VIT_D, a.ln2_g, a.ln2_b, &L.fc1_wf, &L.fc1_cs, &L.fc1_bf))) return r;
+        }
         const float* f2[1] = {a.fc2_w};
         if ((r = upload_bf16(c, f2, r1, 1, VIT_F, &L.fc2_w))) return r;
         if ((r = upload_f32(c, a.fc2_b, VIT_D, &L.fc2_b))) return r;
@@ -430,6 +497,12 @@ int mme_set_gemm_variant(mme_ctx* c, int variant) {
     if (!c) return MME_E_ARG;
     if (variant < 0 || variant > 4) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256 ping-pong), 3 (256x256 streaming) or 4 (256x128, 2 WG/CU)");
     c->gemm_variant = variant;
+    return MME_OK;
+}
+
+int mme_set_ln_fusion(mme_ctx* c, int on) {
+    if (!c) return MME_E_ARG;
+    c->fuse_ln = on != 0;
     return MME_OK;
 }
 

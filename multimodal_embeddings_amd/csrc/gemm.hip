@@ -146,6 +146,8 @@ hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int varia
         case EPI_BIAS_RES: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS_RES>, grid, block, 0, s, g); break;
         case EPI_PATCH: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_PATCH>, grid, block, 0, s, g); break;
         case EPI_F32: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_F32>, grid, block, 0, s, g); break;
+        case EPI_LN_BIAS: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_LN_BIAS>, grid, block, 0, s, g); break;
+        case EPI_LN_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_LN_BIAS_GELU>, grid, block, 0, s, g); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -163,50 +163,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256s(GemmArgs g, int tile
     // are then exactly the PEND youngest vector-memory operations of the wave.
     auto epilogue = [&](int nxt_slot_unused, int cur_slot) {
         const int m0 = cc.m0, n0 = cc.n0;
-        if (EPI != EPI_F32 && EPI != EPI_PATCH && n0 + TN <= g.N && m0 + TM <= g.M) {
-            // wave-uniform row bases (SGPR pairs) + 32-bit lane offsets: saddr addressing.  All
-            // accesses are 16 bytes per lane (see gemm_epilogue.h): 16 stores per wave.
-            const int64_t tile_off = (int64_t)(m0 + wm * 128) * g.ldo + n0 + wn * 64;
-            const int lo0 = fr * (int)g.ldo + row16_col(0, fq), lo1 = fr * (int)g.ldo + row16_col(2, fq);
-            const bf16_t* resb = (const bf16_t*)g.res + tile_off;
-            bf16_t* outb = (bf16_t*)g.out + tile_off;
-            f32x4 bv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + n0 + wn * 64 + fq * 4 + j * 16);
-            uint4 rv[EPI == EPI_BIAS_RES ? 8 : 1][2];
-            if (EPI == EPI_BIAS_RES) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    rv[i][0] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo0);
-                    rv[i][1] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo1);
-                }
-            }
-            PHASE_FENCE();
-            load_A(l2, cur_slot);
-            load_Blo(l2, cur_slot);
-            load_Bhi(l2, cur_slot);
-            PHASE_FENCE();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int jp = 0; jp < 4; jp += 2) {
-                    f32x4 v0 = acc[i][jp] + bv[jp], v1 = acc[i][jp + 1] + bv[jp + 1];
-                    if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            v0[r] = gelu_erf(v0[r]);
-                            v1[r] = gelu_erf(v1[r]);
-                        }
-                    }
-                    if (EPI == EPI_BIAS_RES) {
-                        uint2 rp, rq;
-                        row16_to_pair(rv[i][jp >> 1], rp, rq);
-                        v0 += unpack_bf16x4(rp);
-                        v1 += unpack_bf16x4(rq);
-                    }
-                    *(uint4*)(outb + (int64_t)i * 16 * g.ldo + (jp ? lo1 : lo0)) = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
-                }
-            }
+        if (epi_has_fast_path<EPI>() && n0 + TN <= g.N && m0 + TM <= g.M) {
+            if constexpr (epi_has_fast_path<EPI>()) epilogue_wave_128x64<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [&] {
+                load_A(l2, cur_slot);
+                load_Blo(l2, cur_slot);
+                load_Bhi(l2, cur_slot);
+            });
             pending_stores = true;
         } else {
             load_A(l2, cur_slot);
@@ -366,6 +328,8 @@ hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s, unsig
         case EPI_BIAS_RES: return launch256s<EPI_BIAS_RES>(g, s, stamps);
         case EPI_PATCH: return launch256s<EPI_PATCH>(g, s, stamps);
         case EPI_F32: return launch256s<EPI_F32>(g, s, stamps);
+        case EPI_LN_BIAS: return launch256s<EPI_LN_BIAS>(g, s, stamps);
+        case EPI_LN_BIAS_GELU: return launch256s<EPI_LN_BIAS_GELU>(g, s, stamps);
         default: return hipErrorInvalidValue;
     }
 }

@@ -53,8 +53,15 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, const EpiRow
         }
         return;
     }
-    v += *(const f32x4*)(g.bias + n);
-    if (EPI == EPI_BIAS_GELU) {
+    if (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU) {
+        const float mu = g.ln_stats[2 * (int64_t)m], rs = g.ln_stats[2 * (int64_t)m + 1];
+        const f32x4 sv = *(const f32x4*)(g.colsum + n), bv = *(const f32x4*)(g.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(rs, fmaf(-mu, sv[r], v[r]), bv[r]);
+    } else {
+        v += *(const f32x4*)(g.bias + n);
+    }
+    if (EPI == EPI_BIAS_GELU || EPI == EPI_LN_BIAS_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
@@ -103,3 +110,82 @@ __device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
 }
 // column (within the wave's 64) of this lane's 16-byte piece for the tile pair (jp, jp+1)
 __device__ __forceinline__ int row16_col(int jp, int fq) { return ((fq & 1) ? (jp + 1) * 16 : jp * 16) + (fq >> 1) * 8; }
+
+// Interior-tile epilogue of one wave tile (128 x 64 as acc[8][4] of 16x16 MFMA tiles; row
+// mw + 16 i + fr, columns nw + 16 j + 4 fq ..) for the bias / GELU / residual / LayerNorm-folded
+// epilogues.  All loads are issued first, `between()` runs next (the GEMM kernels request their
+// next LDS-DMA there: vmcnt retires in order and counts stores, so a load issued after a store
+// would wait for it), then 16 fire-and-forget 16-byte stores, which are afterwards exactly the
+// 16 youngest vector-memory operations of the wave.  Straight-line code: a branch would make the
+// compiler re-insert vmcnt(0) at every join.
+template <int EPI, class Between>
+__device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&acc)[8][4], int mw, int nw, int fr, int fq,
+                                                     Between&& between) {
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU,
+                  "epilogue_wave_128x64: unsupported epilogue");
+    constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU;
+    constexpr bool GELU = EPI == EPI_BIAS_GELU || EPI == EPI_LN_BIAS_GELU;
+    // wave-uniform row bases (SGPR pairs) + 32-bit lane offsets: saddr addressing
+    const int64_t tile_off = (int64_t)mw * g.ldo + nw;
+    const int lo0 = fr * (int)g.ldo + row16_col(0, fq), lo1 = fr * (int)g.ldo + row16_col(2, fq);
+    const bf16_t* resb = (const bf16_t*)g.res + tile_off;
+    bf16_t* outb = (bf16_t*)g.out + tile_off;
+    f32x4 bv[4], sv[LN ? 4 : 1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bv[j] = *(const f32x4*)(g.bias + nw + fq * 4 + j * 16);
+        if (LN) sv[j] = *(const f32x4*)(g.colsum + nw + fq * 4 + j * 16);
+    }
+    float2 st[LN ? 8 : 1];
+    if (LN) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st[i] = *(const float2*)(g.ln_stats + 2 * (int64_t)(mw + i * 16 + fr));
+    }
+    uint4 rv[EPI == EPI_BIAS_RES ? 8 : 1][2];
+    if (EPI == EPI_BIAS_RES) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            rv[i][0] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo0);
+            rv[i][1] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo1);
+        }
+    }
+    asm volatile("" ::: "memory");
+    between();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int jp = 0; jp < 4; jp += 2) {
+            f32x4 v0, v1;
+            if (LN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = fmaf(st[i].y, fmaf(-st[i].x, sv[jp][r], acc[i][jp][r]), bv[jp][r]);
+                    v1[r] = fmaf(st[i].y, fmaf(-st[i].x, sv[jp + 1][r], acc[i][jp + 1][r]), bv[jp + 1][r]);
+                }
+            } else {
+                v0 = acc[i][jp] + bv[jp];
+                v1 = acc[i][jp + 1] + bv[jp + 1];
+            }
+            if (GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = gelu_erf(v0[r]);
+                    v1[r] = gelu_erf(v1[r]);
+                }
+            }
+            if (EPI == EPI_BIAS_RES) {
+                uint2 rp, rq;
+                row16_to_pair(rv[i][jp >> 1], rp, rq);
+                v0 += unpack_bf16x4(rp);
+                v1 += unpack_bf16x4(rq);
+            }
+            *(uint4*)(outb + (int64_t)i * 16 * g.ldo + (jp ? lo1 : lo0)) = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
+        }
+    }
+}
+
+template <int EPI>
+constexpr bool epi_has_fast_path() {
+    return EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU;
+}

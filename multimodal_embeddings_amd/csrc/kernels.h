@@ -10,7 +10,11 @@ enum GemmEpilogue {
     EPI_BIAS_GELU = 1,  // out = bf16(gelu_erf(acc + bias[n]))                        (fc1)
     EPI_BIAS_RES = 2,   // out = bf16(acc + bias[n] + res[m,n])   (res may alias out) (o_proj, fc2)
     EPI_PATCH = 3,      // row m=(b,p) -> out row b*197+1+p, + bias[n] + pos[1+p,n]   (patch embed)
-    EPI_F32 = 4         // outf[m,n] = acc                                            (cosine)
+    EPI_F32 = 4,        // outf[m,n] = acc                                            (cosine)
+    // LayerNorm folded into the GEMM that consumes it (A = the raw residual stream x, W' = W*gamma):
+    //   out = bf16(rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n])             (QKV)
+    EPI_LN_BIAS = 5,
+    EPI_LN_BIAS_GELU = 6  // same, then erf-GELU                                      (fc1)
 };
 
 struct GemmArgs {
@@ -24,12 +28,16 @@ struct GemmArgs {
     const float* pos;
     float* outf;
     int64_t ldf;
+    const float* ln_stats;  // [M,2] (mean, rstd) per row, for EPI_LN_*
+    const float* colsum;    // [N] sum_k W'[n,k], for EPI_LN_*
 };
 
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0, unsigned long long* stamps = nullptr);
 
 // LayerNorm over rows of 768 bf16 (f32 statistics), bf16 out.
 hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s);
+// per-row LayerNorm statistics of bf16 rows of 768: stats[row] = (mean, rstd)
+hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats, hipStream_t s);
 // x[b*197 + 0, :] = bf16(cls + pos[0])
 hipError_t launch_cls_rows(void* x, const float* cls, const float* pos, int B, hipStream_t s);
 // final LayerNorm on row b*197+tok, L2 normalise, write f32 and/or bf16

@@ -47,6 +47,36 @@ __global__ __launch_bounds__(256) void layernorm_rows(const bf16_t* __restrict__
     }
 }
 
+// LayerNorm statistics only (mean, rstd) of bf16 rows of 768: the normalisation itself is
+// folded into the GEMM that consumes the row (EPI_LN_*), so the residual stream is read once
+// and nothing is written back but 8 bytes per row.  Same two-pass f32 arithmetic as
+// layernorm_rows, so the folded path sees the statistics LayerNorm would have used.
+__global__ __launch_bounds__(256) void ln_stats_rows(const bf16_t* __restrict__ x, int64_t rows, float eps, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * VIT_D;
+    float v[12];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const bf16x4 p = *(const bf16x4*)(xr + t * 256 + lane * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[t * 4 + j] = (float)p[j];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) s += v[j];
+    const float mean = wave_sum(s) * (1.0f / VIT_D);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const float d = v[j] - mean;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / VIT_D) + eps);
+    if (lane == 0) *(float2*)(stats + 2 * row) = make_float2(mean, rstd);
+}
+
 __global__ __launch_bounds__(256) void cls_rows(bf16_t* __restrict__ x, const float* __restrict__ cls,
                                                 const float* __restrict__ pos, int B) {
     const int lane = threadIdx.x & 63;
@@ -158,6 +188,12 @@ hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(layernorm_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, gamma, beta,
                        (bf16_t*)y, rows, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_stats_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, rows, eps, stats);
     return hipGetLastError();
 }
 

@@ -137,6 +137,21 @@ def test_embed_real_crops_within_1e3_cosine(engine, golden_dir, pool, token):
     assert np.allclose(np.linalg.norm(e32.cpu().numpy(), axis=1), 1.0, atol=1e-5)
 
 
+def test_ln_fusion_on_off_agree(engine, golden_dir):
+    """LayerNorm folded into the GEMMs vs the separate LayerNorm kernel: same embeddings up to bf16 noise."""
+    arrays, _ = _golden_crops(golden_dir)
+    pix, offs, hw = _pack(arrays)
+    want = _oracle_embed(arrays, make_vit_weights(seed=1), "cls")
+    engine.set_ln_fusion(False)
+    a, _ = engine.embed(pix, offs, hw)
+    engine.set_ln_fusion(True)
+    b, _ = engine.embed(pix, offs, hw)
+    torch.cuda.synchronize()
+    ea = _check_embeddings(a.cpu().numpy(), want)
+    eb = _check_embeddings(b.cpu().numpy(), want)
+    assert float((1.0 - (a * b).sum(dim=1)).max()) <= 2e-4, (ea, eb)
+
+
 def test_embed_hot_weights(engine_hot, golden_dir):
     arrays, _ = _golden_crops(golden_dir)
     arrays = arrays[:12]
