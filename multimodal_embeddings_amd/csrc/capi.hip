@@ -341,6 +341,8 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     c->h_crops.resize(n);
     c->h_work.clear();
     size_t tmp_bytes = 0;
+    int table_ints = 16, band_bytes = 16;  // LDS needs of the horizontal pass for this batch
+    constexpr int kBand = 32 * 1024;
     for (int i = 0; i < n; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
         if (h <= 0 || w <= 0 || h > 8000 || w > 8000)
@@ -354,7 +356,14 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
         if (d.new_w != w) {
             d.tmp_off = (int64_t)tmp_bytes;
             tmp_bytes += ((size_t)h * d.new_w * 3 + 15) & ~(size_t)15;
-            for (int r = 0; r < h; r += 16) c->h_work.push_back(HWork{i, r});
+            const int row_bytes = w * 3;
+            int rows = kBand / row_bytes;
+            rows = rows < 1 ? 1 : (rows > 64 ? 64 : rows);
+            for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
+            const int kstride = 2 * ((w + d.new_w - 1) / d.new_w) + 1;
+            if (d.new_w * kstride > table_ints) table_ints = d.new_w * kstride;
+            const int bb = (rows < h ? rows : h) * row_bytes;
+            if (bb > band_bytes) band_bytes = bb;
         }
     }
     int r;
@@ -367,7 +376,8 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     if (!c->h_work.empty())
         HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
     Timed t(c, s, KC_PRE);
-    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(), s));
+    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
+                               table_ints, band_bytes, s));
     HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, s));
     return MME_OK;
 }

@@ -54,10 +54,11 @@ struct CropDesc {  // one per crop, built on the host by capi
     int32_t h, w;      // source size
     int32_t new_h, new_w;
 };
-struct HWork {  // one block of the horizontal pass
-    int32_t crop, row0;
+struct HWork {  // one block of the horizontal pass: a band of source rows of one crop
+    int32_t crop, row0, nrows;
 };
-hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, hipStream_t s);
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
+                           int band_bytes, hipStream_t s);
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
                                     const float* lut /*[3,256]*/, void* patches, hipStream_t s);
 

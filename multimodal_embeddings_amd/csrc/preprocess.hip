@@ -25,10 +25,8 @@
 namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
-constexpr int MAX_DIM = 8000;      // the reference caps crops at 8000 px (embedder.py:110-114)
 constexpr int MAX_TAPS = 160;      // window <= 2*ceil(scale)+1 and scale < 2*MAX_DIM/224
-constexpr int H_TABLE = 2 * MAX_DIM + 3 * VIT_IMG + 64;  // out * (2*ceil(in/out)+1) <= 2*in + 3*out
-constexpr int H_ROWS = 16;         // source rows per resize_h workgroup
+constexpr int V_WINDOW = 36 * 1024; // bytes of source rows a resize_v workgroup stages in LDS
 
 struct Taps {
     int xmin, n;
@@ -69,43 +67,42 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// Horizontal pass.  One workgroup = one band of source rows of one crop; the band is a single
+// contiguous byte range (rows are contiguous), fetched with one sweep of 16-byte loads into LDS
+// (all loads in flight at once), then every (row, x, channel) output of the band is computed
+// from LDS in parallel.  Band height is chosen on the host so that a band is <= H_BAND bytes.
 __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
-                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work) {
+                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work, int table_ints) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HWork wk = work[blockIdx.x];
     const CropDesc c = crops[wk.crop];
     const int tid = threadIdx.x;
     const int row_bytes = c.w * 3;
-    // LDS carve: [224] Taps, coefficient table with a per-crop stride, then one source row
+    // LDS carve: [224] Taps | coefficient table (per-launch size) | band
     Taps* taps = (Taps*)smem;
     int* kk = (int*)(smem + VIT_IMG * sizeof(Taps));
-    uint8_t* rowbuf = (uint8_t*)(smem + VIT_IMG * sizeof(Taps) + H_TABLE * sizeof(int));
+    uint8_t* band = (uint8_t*)(smem + VIT_IMG * sizeof(Taps) + (size_t)table_ints * sizeof(int));
     const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;  // >= 2*ceil(max(scale,1))+1
     if (tid < c.new_w) taps[tid] = compute_taps(c.w, c.new_w, tid, kk + tid * kstride);
+    const uint8_t* src = pix + c.src_off + (int64_t)wk.row0 * row_bytes;
+    const int nbytes = wk.nrows * row_bytes;
+    const uintptr_t a0 = (uintptr_t)src & ~(uintptr_t)15;
+    const int lead = (int)((uintptr_t)src - a0);
+    const int nvec = (lead + nbytes + 15) >> 4;
+    for (int i = tid; i < nvec; i += 256) ((uint4*)band)[i] = ((const uint4*)a0)[i];
     __syncthreads();
-    const uint8_t* src = pix + c.src_off;
-    uint8_t* dst = tmp + c.tmp_off;
-    const int rows = min(H_ROWS, c.h - wk.row0);
-    for (int yy = 0; yy < rows; ++yy) {
-        const int y = wk.row0 + yy;
-        const uint8_t* srow = src + (int64_t)y * row_bytes;
-        // the row start is only byte aligned: copy with 4-byte words from the aligned base
-        const uintptr_t a0 = (uintptr_t)srow & ~(uintptr_t)3;
-        const int lead = (int)((uintptr_t)srow - a0);
-        const int nwords = (lead + row_bytes + 3) >> 2;
-        for (int i = tid; i < nwords; i += 256) ((uint32_t*)rowbuf)[i] = ((const uint32_t*)a0)[i];
-        __syncthreads();
-        const uint8_t* rb = rowbuf + lead;
-        for (int e = tid; e < c.new_w * 3; e += 256) {
-            const int xx = e / 3, ch = e - xx * 3;
-            const Taps t = taps[xx];
-            const int* k = kk + xx * kstride;
-            int ss0 = 1 << (PRECISION_BITS - 1);
-            const uint8_t* p = rb + t.xmin * 3 + ch;
-            for (int x = 0; x < t.n; ++x) ss0 += (int)p[x * 3] * k[x];
-            dst[(int64_t)y * c.new_w * 3 + e] = clip8(ss0);
-        }
-        __syncthreads();
+    const uint8_t* bb = band + lead;
+    const int out_row = c.new_w * 3;
+    uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * out_row;
+    for (int e = tid; e < wk.nrows * out_row; e += 256) {
+        const int y = e / out_row, rem = e - y * out_row;
+        const int xx = rem / 3, ch = rem - xx * 3;
+        const Taps t = taps[xx];
+        const int* k = kk + xx * kstride;
+        int ss0 = 1 << (PRECISION_BITS - 1);
+        const uint8_t* p = bb + y * row_bytes + t.xmin * 3 + ch;
+        for (int x = 0; x < t.n; ++x) ss0 += (int)p[x * 3] * k[x];
+        dst[e] = clip8(ss0);
     }
 }
 
@@ -116,6 +113,7 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
     __shared__ Taps taps[VIT_PATCH];
     __shared__ int kk[VIT_PATCH * MAX_TAPS];
     __shared__ float slut[3 * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t window[V_WINDOW + 32];  // source rows feeding this band
     const int crop = blockIdx.x / VIT_GRID, py = blockIdx.x - crop * VIT_GRID;
     const CropDesc c = crops[crop];
     const int tid = threadIdx.x;
@@ -135,23 +133,55 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
         // unchanged 224-wide rows (the synthetic 224x224 workload): one contiguous 10752-byte band
         for (int e = tid; e < VIT_PATCH * VIT_IMG * 3 / 16; e += 256) ((uint4*)canvas)[e] = ((const uint4*)band)[e];
     } else
-    for (int e = tid; e < VIT_PATCH * VIT_IMG * 3; e += 256) {
-        const int ky = e / (VIT_IMG * 3), rem = e - ky * (VIT_IMG * 3);
-        const int yy = py * VIT_PATCH + ky;
-        uint8_t v = 0;
-        if (yy < c.new_h && rem < src_row_bytes) {
-            if (!vpass) {
-                v = src[(int64_t)yy * src_row_bytes + rem];
+    {
+        // vertical pass (or row copy): the source rows this band needs form one contiguous byte
+        // range; stage it in LDS with 16-byte loads when it fits, else read global directly
+        const int y_first = py * VIT_PATCH, y_last = min(y_first + VIT_PATCH, c.new_h) - 1;
+        int r0 = 0, r1 = -1;  // source row range [r0, r1]
+        if (y_last >= y_first) {
+            if (vpass) {
+                r0 = taps[0].xmin;
+                r1 = taps[y_last - y_first].xmin + taps[y_last - y_first].n - 1;
             } else {
-                const Taps t = taps[ky];
-                const int* k = kk + ky * MAX_TAPS;
-                int ss0 = 1 << (PRECISION_BITS - 1);
-                const uint8_t* p = src + (int64_t)t.xmin * src_row_bytes + rem;
-                for (int y = 0; y < t.n; ++y) ss0 += (int)p[(int64_t)y * src_row_bytes] * k[y];
-                v = clip8(ss0);
+                r0 = y_first;
+                r1 = y_last;
             }
         }
-        canvas[e] = v;
+        const int64_t wbytes = (int64_t)(r1 - r0 + 1) * src_row_bytes;
+        const uint8_t* wsrc = src + (int64_t)r0 * src_row_bytes;
+        const bool staged = wbytes > 0 && wbytes <= V_WINDOW;
+        int lead = 0;
+        if (staged) {
+            const uintptr_t a0 = (uintptr_t)wsrc & ~(uintptr_t)15;
+            lead = (int)((uintptr_t)wsrc - a0);
+            const int nvec = (int)((lead + wbytes + 15) >> 4);
+            for (int i = tid; i < nvec; i += 256) ((uint4*)window)[i] = ((const uint4*)a0)[i];
+        }
+        __syncthreads();
+        const uint8_t* wb = window + lead;
+        for (int e = tid; e < VIT_PATCH * VIT_IMG * 3; e += 256) {
+            const int ky = e / (VIT_IMG * 3), rem = e - ky * (VIT_IMG * 3);
+            const int yy = py * VIT_PATCH + ky;
+            uint8_t v = 0;
+            if (yy < c.new_h && rem < src_row_bytes) {
+                if (!vpass) {
+                    v = staged ? wb[(yy - r0) * src_row_bytes + rem] : src[(int64_t)yy * src_row_bytes + rem];
+                } else {
+                    const Taps t = taps[ky];
+                    const int* k = kk + ky * MAX_TAPS;
+                    int ss0 = 1 << (PRECISION_BITS - 1);
+                    if (staged) {
+                        const uint8_t* p = wb + (t.xmin - r0) * src_row_bytes + rem;
+                        for (int y = 0; y < t.n; ++y) ss0 += (int)p[y * src_row_bytes] * k[y];
+                    } else {
+                        const uint8_t* p = src + (int64_t)t.xmin * src_row_bytes + rem;
+                        for (int y = 0; y < t.n; ++y) ss0 += (int)p[(int64_t)y * src_row_bytes] * k[y];
+                    }
+                    v = clip8(ss0);
+                }
+            }
+            canvas[e] = v;
+        }
     }
     __syncthreads();
     // 14 patches x 768 values; a thread emits 8 consecutive kx of one (patch, c, ky)
@@ -169,18 +199,19 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
 
 }  // namespace
 
-hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, hipStream_t s) {
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
+                           int band_bytes, hipStream_t s) {
     if (nwork <= 0) return hipSuccess;
-    // Taps table + coefficient table + one source row of up to 8000 px (reference cap,
-    // embedder.py:110-114) with alignment slack
-    const size_t smem = VIT_IMG * sizeof(Taps) + H_TABLE * sizeof(int) + MAX_DIM * 3 + 32;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // Taps table + coefficient table (largest of the batch) + one band (+ alignment slack)
+    const size_t smem = VIT_IMG * sizeof(Taps) + (size_t)table_ints * sizeof(int) + (size_t)band_bytes + 48;
+    if (smem > 160 * 1024) return hipErrorInvalidValue;
+    static size_t attr_set = 0;
+    if (smem > attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)resize_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set = smem;
     }
-    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work);
+    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints);
     return hipGetLastError();
 }
 
