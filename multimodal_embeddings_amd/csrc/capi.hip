@@ -343,6 +343,7 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     size_t tmp_bytes = 0;
     int table_ints = 16, band_bytes = 16;  // LDS needs of the horizontal pass for this batch
     constexpr int kBand = 32 * 1024;
+    bool any_resize = false;
     for (int i = 0; i < n; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
         if (h <= 0 || w <= 0 || h > 8000 || w > 8000)
@@ -352,6 +353,7 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
         d.h = h;
         d.w = w;
         fit_to_canvas(h, w, &d.new_h, &d.new_w);
+        if (h != VIT_IMG || w != VIT_IMG) any_resize = true;
         d.tmp_off = 0;
         if (d.new_w != w) {
             d.tmp_off = (int64_t)tmp_bytes;
@@ -378,7 +380,7 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     Timed t(c, s, KC_PRE);
     HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
                                table_ints, band_bytes, s));
-    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, s));
+    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, any_resize, s));
     return MME_OK;
 }
 

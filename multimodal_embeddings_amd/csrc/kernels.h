@@ -60,7 +60,7 @@ struct HWork {  // one block of the horizontal pass: a band of source rows of on
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
                            int band_bytes, hipStream_t s);
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
-                                    const float* lut /*[3,256]*/, void* patches, hipStream_t s);
+                                    const float* lut /*[3,256]*/, void* patches, bool any_resize, hipStream_t s);
 
 struct PageSimArgs {
     const void* emb;        // bf16 [N, d]

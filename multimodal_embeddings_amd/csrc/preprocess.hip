@@ -108,12 +108,12 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
 
 __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
                                                          const CropDesc* __restrict__ crops, const float* __restrict__ lut,
-                                                         bf16_t* __restrict__ patches) {
+                                                         bf16_t* __restrict__ patches, int window_bytes) {
     __shared__ __attribute__((aligned(16))) uint8_t canvas[VIT_PATCH * VIT_IMG * 3 + 16];
     __shared__ Taps taps[VIT_PATCH];
     __shared__ int kk[VIT_PATCH * MAX_TAPS];
     __shared__ float slut[3 * 256];
-    __shared__ __attribute__((aligned(16))) uint8_t window[V_WINDOW + 32];  // source rows feeding this band
+    extern __shared__ __attribute__((aligned(16))) uint8_t window[];  // source rows feeding this band (0 bytes for all-224 batches)
     const int crop = blockIdx.x / VIT_GRID, py = blockIdx.x - crop * VIT_GRID;
     const CropDesc c = crops[crop];
     const int tid = threadIdx.x;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
         }
         const int64_t wbytes = (int64_t)(r1 - r0 + 1) * src_row_bytes;
         const uint8_t* wsrc = src + (int64_t)r0 * src_row_bytes;
-        const bool staged = wbytes > 0 && wbytes <= V_WINDOW;
+        const bool staged = wbytes > 0 && wbytes <= window_bytes;
         int lead = 0;
         if (staged) {
             const uintptr_t a0 = (uintptr_t)wsrc & ~(uintptr_t)15;
@@ -216,8 +216,12 @@ hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* cro
 }
 
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n, const float* lut,
-                                    void* patches, hipStream_t s) {
+                                    void* patches, bool any_resize, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(resize_v_patchify, dim3(n * VIT_GRID), dim3(256), 0, s, pix, tmp, crops, lut, (bf16_t*)patches);
+    // the LDS window is only needed when some crop is resized or partially fills the canvas; the
+    // all-224x224 batch keeps the small footprint (more workgroups per CU for a pure stream)
+    const int window = any_resize ? V_WINDOW : 0;
+    hipLaunchKernelGGL(resize_v_patchify, dim3(n * VIT_GRID), dim3(256), window ? window + 32 : 0, s, pix, tmp, crops, lut,
+                       (bf16_t*)patches, window);
     return hipGetLastError();
 }
