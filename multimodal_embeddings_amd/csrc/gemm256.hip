@@ -44,7 +44,7 @@ constexpr int R_ALO = 0, R_AHI = HALF, R_BLO = 2 * HALF, R_BHI = 3 * HALF;
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles_m, int tiles_n, int dbg) {
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles_m, int tiles_n, int gn, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,8 +72,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
     };
     auto make_ctx = [&](int tile) {
         TileCtx c;
+        // ids are ordered (column group, row panel, column in group): an XCD's contiguous id range
+        // stays inside one group of `gn` column tiles, whose weight rows then live in its L2
         const int id = xcd_remap(tile, ntiles);
-        const int tm = id / tiles_n, tn = id - tm * tiles_n;
+        const int gsz = tiles_m * gn;
+        const int grp = id / gsz, rem = id - grp * gsz;
+        const int gw = min(gn, tiles_n - grp * gn);
+        const int tm = rem / gw, tn = grp * gn + (rem - tm * gw);
         c.m0 = tm * TM;
         c.n0 = tn * TN;
         c.Ag = (const char*)g.A + (size_t)(dbg == 2 ? 0 : c.m0) * ldb;
@@ -277,7 +282,14 @@ hipError_t launch256(const GemmArgs& g, hipStream_t s) {
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
     static const int dbg = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;  // timing experiments only
-    hipLaunchKernelGGL(gemm_bf16_tn_256<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, dbg);
+    static const int gn_env = getenv("MME_GEMM_GN") ? atoi(getenv("MME_GEMM_GN")) : 0;
+    // column-group width: the group's weight rows (gn x 256 x K bf16) should stay resident in one
+    // XCD's 4 MiB L2 next to the streaming A panels and output lines; never split below 3 tiles
+    // (PMC, fc1 4096 crops: L2-miss fetch 15.4 GB at gn = 12 -> 6.2 GB at gn = 6, same time)
+    int gn = gn_env > 0 ? gn_env : (int)((2400 * 1024) / ((size_t)TN * g.K * 2));
+    if (gn < 3) gn = 3;
+    if (gn > tiles_n) gn = tiles_n;
+    hipLaunchKernelGGL(gemm_bf16_tn_256<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, gn, dbg);
     return hipGetLastError();
 }
 
