@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--crops", type=int, default=CROPS_PER_GPU, help="crops per GPU (headline config: 4096)")
     ap.add_argument("--chunk", type=int, default=0, help="crops per encoder pass (0 = library default)")
-    ap.add_argument("--gemm-variant", type=int, default=0, help="0 auto, 1 128x128, 2 256 ping-pong, 3 256 streaming")
+    ap.add_argument("--gemm-variant", type=int, default=0, help="0 auto, 1 128x128, 2 256x256 2-slot ring, 3 256x256 3-deep activation ring")
     ap.add_argument("--no-ln-fusion", action="store_true", help="separate LayerNorm kernel instead of folding it into the GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

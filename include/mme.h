@@ -86,7 +86,8 @@ int mme_set_normalisation(mme_ctx* ctx, const float mean[3], const float std[3])
 int mme_set_chunk(mme_ctx* ctx, int crops_per_pass);
 
 /* Tuning / test knob: which MFMA GEMM tiling serves K2/K4/K6/K7/K9.  0 = by shape (default),
- * 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel.  Results are bit-identical across variants
+ * 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel with a 2-slot LDS ring, 3 = the same with a
+ * 3-deep activation ring (the default for large problems).  Results are bit-identical across variants
  * (same MFMA instruction, same K order per output element). */
 int mme_set_gemm_variant(mme_ctx* ctx, int variant);
 
@@ -173,11 +174,8 @@ int mme_cluster_pages(mme_ctx* ctx, const double* S_dev, int P, int n_clusters, 
 
 /* Diagnostic: time one MFMA GEMM shape on random bf16 data (allocates its own operands;
  * synchronous).  epilogue 0 bias, 1 bias+GELU, 2 bias+residual, 3 patch-embed, 4 f32 out;
- * variant as mme_set_gemm_variant.  stamps_host (optional, uint64[stamps_words]): in-kernel cycle
- * stamps of the streaming kernel, 8 words per wave: total, LDS-drain, DMA-wait, barrier, epilogue
- * cycles and K-tile count. */
-int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms,
-                   uint64_t* stamps_host, int stamps_words);
+ * variant as mme_set_gemm_variant. */
+int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms);
 
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
  * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster */

@@ -57,7 +57,7 @@ EXPORTS = {
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_cluster_pages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p, C.c_int]),
+    "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
     "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -263,14 +263,11 @@ class Engine:
         sc = scores.cpu().numpy()
         return labels.cpu().numpy().tolist(), int(k.item()), [(i, float(sc[i])) for i in range(2, 16) if sc[i] == sc[i]]
 
-    def gemm_bench(self, M, N, K, epilogue=0, variant=0, iters=10, stamps=False):
-        """(avg ms, TFLOP/s[, stamps uint64[256*8, 8]]) for one GEMM shape on random data."""
-        ms = C.c_double()
-        st = np.zeros((256 * 8, 8), dtype=np.uint64) if stamps else None
-        self._check(self.lib.mme_gemm_bench(self.h, M, N, K, epilogue, variant, iters, C.byref(ms),
-                                            st.ctypes.data if stamps else None, st.size if stamps else 0), "mme_gemm_bench")
-        tf = 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
-        return (ms.value, tf, st) if stamps else (ms.value, tf)
+    def gemm_bench(self, M, N, K, epilogue=0, variant=0, iters=10):
+        """(avg ms, TFLOP/s) for one GEMM shape on random data."""
+        ms = C.c_double(0)
+        self._check(self.lib.mme_gemm_bench(self.h, M, N, K, epilogue, variant, iters, C.byref(ms)), "mme_gemm_bench")
+        return ms.value, 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
 
     # ---- timing ------------------------------------------------------------------------------------
     def profile(self, on: bool):

@@ -507,7 +507,7 @@ int mme_set_normalisation(mme_ctx* c, const float mean[3], const float stdv[3]) 
 
 int mme_set_gemm_variant(mme_ctx* c, int variant) {
     if (!c) return MME_E_ARG;
-    if (variant < 0 || variant > 4) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256 ping-pong), 3 (256x256 streaming) or 4 (256x128, 2 WG/CU)");
+    if (variant < 0 || variant > 3) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256, 2-slot ring) or 3 (256x256, 3-deep activation ring)");
     c->gemm_variant = variant;
     return MME_OK;
 }
@@ -667,13 +667,13 @@ int mme_cluster_pages(mme_ctx* c, const double* S, int P, int n_clusters, int mo
     return MME_OK;
 }
 
-int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms, uint64_t* stamps_host, int stamps_words) {
+int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms) {
     if (!c || !avg_ms) return MME_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0 || iters < 1 || epilogue < 0 || epilogue > 4)
         return fail(c, MME_E_ARG, "mme_gemm_bench: bad shape / epilogue");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t a_bytes = (size_t)M * K * 2, w_bytes = (size_t)N * K * 2, o_bytes = (size_t)(M + 256) * N * 4;
-    void *A = nullptr, *W = nullptr, *O = nullptr, *B = nullptr, *P = nullptr, *ST = nullptr;
+    void *A = nullptr, *W = nullptr, *O = nullptr, *B = nullptr, *P = nullptr;
     std::vector<uint16_t> h(((a_bytes > w_bytes ? a_bytes : w_bytes) / 2));
     uint64_t x = 0x9E3779B97F4A7C15ull;
     auto fill = [&](size_t n) {  // uniform [-1,1) bf16 (guide: bench on random data, never zeros)
@@ -687,14 +687,12 @@ int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, i
     hipEvent_t e0 = nullptr, e1 = nullptr;
     do {
         if (hipMalloc(&A, a_bytes) != hipSuccess || hipMalloc(&W, w_bytes) != hipSuccess || hipMalloc(&O, o_bytes) != hipSuccess ||
-            hipMalloc(&B, (size_t)N * 4) != hipSuccess || hipMalloc(&P, (size_t)VIT_T * N * 4) != hipSuccess ||
-            hipMalloc(&ST, 256 * 8 * 8 * 8) != hipSuccess) { rc = fail(c, MME_E_NOMEM, "mme_gemm_bench: hipMalloc"); break; }
+            hipMalloc(&B, (size_t)N * 4) != hipSuccess || hipMalloc(&P, (size_t)VIT_T * N * 4) != hipSuccess) { rc = fail(c, MME_E_NOMEM, "mme_gemm_bench: hipMalloc"); break; }
         fill(a_bytes / 2);
         if (hipMemcpy(A, h.data(), a_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, MME_E_HIP, "memcpy"); break; }
         fill(w_bytes / 2);
         if (hipMemcpy(W, h.data(), w_bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, MME_E_HIP, "memcpy"); break; }
         (void)hipMemset(O, 0, o_bytes); (void)hipMemset(B, 0, (size_t)N * 4); (void)hipMemset(P, 0, (size_t)VIT_T * N * 4);
-        (void)hipMemset(ST, 0, 256 * 8 * 8 * 8);
         GemmArgs g{};
         g.A = A; g.W = W; g.M = M; g.N = N; g.K = K; g.bias = (const float*)B; g.out = O; g.ldo = N; g.res = O; g.pos = (const float*)P;
         g.outf = (float*)O; g.ldf = N;
@@ -710,16 +708,10 @@ int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, i
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         *avg_ms = ms / iters;
-        if (stamps_host && stamps_words > 0) {
-            (void)launch_gemm(epilogue, g, s, variant, (unsigned long long*)ST);
-            (void)hipDeviceSynchronize();
-            const size_t n = (size_t)stamps_words * 8 < 256 * 8 * 8 * 8 ? (size_t)stamps_words * 8 : 256 * 8 * 8 * 8;
-            (void)hipMemcpy(stamps_host, ST, n, hipMemcpyDeviceToHost);
-        }
     } while (0);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    for (void* p : {A, W, O, B, P, ST}) if (p) (void)hipFree(p);
+    for (void* p : {A, W, O, B, P}) if (p) (void)hipFree(p);
     return rc;
 }
 

@@ -120,23 +120,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
 }  // namespace
 
 hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
-hipError_t launch_gemm256s(int epilogue, const GemmArgs& g, hipStream_t s, unsigned long long* stamps);
-hipError_t launch_gemm256x128(int epilogue, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s);
 
-// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel, 3 = 256x256 streaming kernel, 4 = 256x128 two-workgroups-per-CU kernel
-hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant, unsigned long long* stamps) {
+// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel with a 2-slot LDS ring,
+// 3 = the same with a 3-deep activation ring (all 160 KiB of LDS)
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (variant == 0) {
         // the 256 kernel wants at least ~2 tiles per CU to amortise its prologue
         const int64_t tiles256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256);
-        variant = tiles256 >= 256 ? 2 : 1;
+        variant = tiles256 >= 256 ? 3 : 1;
     }
     if (variant == 2) return launch_gemm256(epilogue, g, s);
-    if (variant == 4) return (g.K % 64) == 0 ? launch_gemm256x128(epilogue, g, s) : launch_gemm256(epilogue, g, s);
-    if (variant == 3) {
-        // the streaming kernel needs an even number of K-tiles; otherwise the ping-pong kernel serves
-        return (g.K % 128) == 0 ? launch_gemm256s(epilogue, g, s, stamps) : launch_gemm256(epilogue, g, s);
-    }
+    if (variant == 3) return launch_gemm256r(epilogue, g, s);
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

@@ -32,7 +32,7 @@ struct GemmArgs {
     const float* colsum;    // [N] sum_k W'[n,k], for EPI_LN_*
 };
 
-hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0, unsigned long long* stamps = nullptr);
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0);
 
 // LayerNorm over rows of 768 bf16 (f32 statistics), bf16 out.
 hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s);

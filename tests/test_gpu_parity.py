@@ -191,7 +191,7 @@ def test_embed_chunking_and_ragged_batch(engine):
     assert e0.shape == (0, 768)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_cosine_matches_f64(engine, variant):
     engine.set_gemm_variant(variant)
     rng = np.random.default_rng(2)
@@ -223,7 +223,7 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
         b = engine.normalise_rows(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda())
         engine.set_gemm_variant(1)
         ref = engine.cosine(a, b)
-        for variant in (2, 3, 4):
+        for variant in (2, 3):
             engine.set_gemm_variant(variant)
             for _ in range(reps):
                 got = engine.cosine(a, b)
@@ -232,7 +232,7 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
     pix, offs, hw = _pack(arrays)
     engine.set_gemm_variant(1)
     e1, _ = engine.embed(pix, offs, hw)
-    for variant in (2, 3, 4):
+    for variant in (2, 3):
         engine.set_gemm_variant(variant)
         for _ in range(3):
             e2, _ = engine.embed(pix, offs, hw)
@@ -242,7 +242,7 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
     pixb, offsb, hwb = _pack(list(crops))
     engine.set_gemm_variant(1)
     r1, _ = engine.embed(pixb, offsb, hwb)
-    for variant in (2, 3, 4):
+    for variant in (2, 3):
         engine.set_gemm_variant(variant)
         r2, _ = engine.embed(pixb, offsb, hwb)
         assert torch.equal(r1, r2), variant
