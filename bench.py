@@ -34,6 +34,21 @@ CROPS_PER_GPU = 4096
 FLOP_FORWARD_PER_CROP = 35_126_083_584  # SURVEY.md §8d (2*MAC, LN/softmax/GELU excluded)
 FLOP_GEMM_PER_CROP = 231_211_008 + 12 * (697_171_968 + 232_390_656 + 2 * 929_562_624)  # K2,K4,K6,K7 launches
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
+# algorithmic HBM bytes of the same launches per crop: every activation operand read once, every
+# output written once (bf16), residual read once; weights (85.8 M bf16 per forward pass) added per pass
+BYTES_GEMM_PER_CROP = 12 * 197 * 2 * ((768 + 2304) + 3 * 768 + (768 + 3072) + (3072 + 2 * 768)) + (196 + 197) * 768 * 2
+BYTES_GEMM_WEIGHTS = 2 * (768 * 768 + 12 * (2304 * 768 + 768 * 768 + 2 * 3072 * 768))
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "round1_v8_gemm_traffic.json")  # tools/traffic_json.py, PMC passes of this bench
+
+
+def measured_traffic():
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (separate runs of this same command; 2 x FETCH_SIZE + WRITE_SIZE, see profiles/README.md)."""
+    try:
+        with open(TRAFFIC_PROFILE) as fh:
+            return float(json.load(fh)["gemm_traffic_per_launch"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def cpu_baseline(sample_crops: np.ndarray, weights, budget_s: float = 20.0):
@@ -153,7 +168,9 @@ def main():
             "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": (ach / MFMA_BF16_PEAK_TFLOPS) if ach else None,
-            "traffic": None,
+            "traffic": measured_traffic() if n == CROPS_PER_GPU else None,
+            "traffic_unit": "bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_v8_gemm_traffic.json)",
+            "algorithmic_bytes_per_launch": (BYTES_GEMM_PER_CROP * n + BYTES_GEMM_WEIGHTS * (gemm_launches / steps / 49.0)) / (gemm_launches / steps) if gemm_launches else None,
             "launches_per_step": gemm_launches / steps,
             "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
             "flop_per_launch_avg": FLOP_GEMM_PER_CROP * n / (gemm_launches / steps) if gemm_launches else None,
