@@ -33,6 +33,7 @@ constexpr int BUF_BYTES = 2 * KV_BYTES;
 constexpr int NPIECE = 25;             // 25 x 8 rows = 200 >= 197
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
@@ -50,11 +51,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         *(uint4*)(lds + buf * BUF_BYTES + KV_BYTES + (200 + r) * ROWB + c * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // DMA of one head: 25 K pieces + 25 V pieces (8 rows x 128 B each) over 8 waves
+    // DMA of one head: 25 K pieces + 25 V pieces (8 rows x 128 B each), all issued by wave 7: an
+    // LDS-DMA piece stalls its issuer for ~100+ cycles, which the seven computing waves cannot afford
     auto dma_head = [&](int h, int buf) {
         const char* hb = base + h * ROWB;
         char* kdst = lds + buf * BUF_BYTES;
-        for (int p = wave; p < 2 * NPIECE; p += 8) {
+        if (wave != 7) return;  // the wave without a query block does all the staging
+        for (int p = 0; p < 2 * NPIECE; ++p) {
             const bool isv = p >= NPIECE;
             const int pp = isv ? p - NPIECE : p;
             const int row = pp * 8 + (lane >> 3);
@@ -106,61 +109,92 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         }
         if (active) {
             f32x16 s[7];
+            // S^T tiles; the K fragments of tile kt+1 are requested before the MFMAs of tile kt so
+            // that no MFMA waits on the ds_read issued just before it
+            bf16x8 kf[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[0][ks] = *(const bf16x8*)(Kl + r * ROWB + (((2 * ks + hh) ^ ksw) << 4));
 #pragma unroll
             for (int kt = 0; kt < 7; ++kt) {
+                if (kt + 1 < 7) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        kf[(kt + 1) & 1][ks] = *(const bf16x8*)(Kl + ((kt + 1) * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                }
                 f32x16 a;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) a[e] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(Kl + (kt * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
-                }
+                for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt & 1][ks], qf[ks], a, 0, 0, 0);
                 s[kt] = a;
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding
+            // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding: of the last
+            // tile only e = 0..3 can be valid (keys 192..195 in the lower lane half, 196 in the upper)
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 7; ++kt)
+            for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const bool valid = (kt < 6) || ((e >> 2) == 0 && (e & 3) + 4 * hh < VIT_T - 192);
-                    if (valid) mx = fmaxf(mx, s[kt][e]);
-                }
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e + 4 * hh < VIT_T - 192) mx = fmaxf(mx, s[6][e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mxs = mx * sc;
-            float sum = 0.f;
+            const f32x2 sc2 = {sc, sc}, nmx2 = {-mx * sc, -mx * sc};
+            f32x2 sum2 = {0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 7; ++kt)
+            for (int kt = 0; kt < 6; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const bool valid = (kt < 6) || ((e >> 2) == 0 && (e & 3) + 4 * hh < VIT_T - 192);
-                    const float p = valid ? __builtin_amdgcn_exp2f(fmaf(s[kt][e], sc, -mxs)) : 0.f;
-                    s[kt][e] = p;
-                    sum += p;
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 t = __builtin_elementwise_fma(f32x2{s[kt][e], s[kt][e + 1]}, sc2, nmx2);
+                    const f32x2 p = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                    s[kt][e] = p.x;
+                    s[kt][e + 1] = p.y;
+                    sum2 += p;
                 }
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 t = __builtin_elementwise_fma(f32x2{s[6][e], s[6][e + 1]}, sc2, nmx2);
+                f32x2 p = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                if (!(e + 4 * hh < VIT_T - 192)) p.x = 0.f;
+                if (!(e + 1 + 4 * hh < VIT_T - 192)) p.y = 0.f;
+                s[6][e] = p.x;
+                s[6][e + 1] = p.y;
+                sum2 += p;
+            }
+#pragma unroll
+            for (int e = 4; e < 16; ++e) s[6][e] = 0.f;
+            float sum = sum2.x + sum2.y;
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
 
             f32x16 o[2];
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
+            // 13 steps of 16 keys (keys 208..223 are all padding); the V^T fragments of step i+1 are
+            // requested before the MFMAs of step i
+            s16x8 vf[2][2];
+            auto read_v = [&](int i, s16x8 (&dst)[2]) {
 #pragma unroll
-            for (int kt = 0; kt < 7; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * s2 + j];
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) {
-                        const char* va = Vl + (kt * 32 + s2 * 16) * ROWB + (db ? v_off1 : v_off0);
-                        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
-                        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * ROWB));
-                        const s16x8 vc = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vc), pf, o[db], 0, 0, 0);
-                    }
+                for (int db = 0; db < 2; ++db) {
+                    const char* va = Vl + i * 16 * ROWB + (db ? v_off1 : v_off0);
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * ROWB));
+                    dst[db] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
+            };
+            read_v(0, vf[0]);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) {
+                if (i + 1 < 13) read_v(i + 1, vf[(i + 1) & 1]);
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[i >> 1][8 * (i & 1) + j];
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i & 1][db]), pf, o[db], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if (h + 1 < VIT_H) {  // before the stores: the wait for the prefetched Q must not cover them
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
