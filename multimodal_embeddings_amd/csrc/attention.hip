@@ -87,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
     }
 
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses VALU arbitration otherwise
     for (int h = 0; h < VIT_H; ++h) {
         const int buf = h & 1;
         const char* Kl = lds + buf * BUF_BYTES;
