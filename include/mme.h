@@ -172,14 +172,32 @@ int mme_page_similarity(mme_ctx* ctx, const uint16_t* emb_dev, int64_t N, int d,
 int mme_cluster_pages(mme_ctx* ctx, const double* S_dev, int P, int n_clusters, int mode, int32_t* labels_dev,
                       int32_t* k_dev, double* scores_dev, void* stream);
 
+/* K12 ranked neighbour lists.  Replaces the query + filter loops of
+ * create_region_cross_comparison (region_compare.py:160-353) and create_cross_comparison
+ * (cross_compare.py:109-235): for each query row r in [row0, row0 + nrows) of the L2-normalised
+ * bf16 rows emb_dev[N, d], take the `fetch` nearest rows by cosine -- r itself included, as the
+ * store's query returns it; order = stable ascending distance, i.e. similarity descending, index
+ * ascending on ties -- drop r unless keep_self (region_compare.py:244), drop rows whose group id
+ * equals r's (same parent page, :260; group_dev may be NULL), drop similarities outside
+ * [min_sim, max_sim] (:269), keep the first top_n (:352).
+ *   fetch, top_n  1..128 (the reference uses fetch = min(3 top_n, 100), top_n = 10)
+ *   idx_dev   int32[nrows, top_n] row indices, -1 padded;  sim_dev  float[nrows, top_n] cosine
+ * The [rows, N] cosine block is produced chunk-wise by the MFMA GEMM into an internal workspace
+ * (<= 2 GiB) and consumed by a one-wave-per-row streaming top-k; S is never materialised.
+ * Multi-GPU: each rank passes its own [row0, row0 + nrows) against the all-gathered emb. */
+int mme_neighbours(mme_ctx* ctx, const uint16_t* emb_dev, int N, int d, const int32_t* group_dev, int row0, int nrows,
+                   int fetch, int top_n, int keep_self, float min_sim, float max_sim, int32_t* idx_dev, float* sim_dev,
+                   void* stream);
+
 /* Diagnostic: time one MFMA GEMM shape on random bf16 data (allocates its own operands;
  * synchronous).  epilogue 0 bias, 1 bias+GELU, 2 bias+residual, 3 patch-embed, 4 f32 out;
  * variant as mme_set_gemm_variant. */
 int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms);
 
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
- * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster */
-#define MME_NUM_KERNEL_CLASSES 8
+ * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster,
+ * 8 neighbours */
+#define MME_NUM_KERNEL_CLASSES 9
 int mme_profile_enable(mme_ctx* ctx, int on);
 int mme_profile_reset(mme_ctx* ctx);
 /* synchronises the recorded events; ms[c] = total ms, launches[c] = launch count per class */

@@ -14,8 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmme.so")
 
-NUM_KERNEL_CLASSES = 8
-KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "cluster")
+NUM_KERNEL_CLASSES = 9
+KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "cluster", "neighbours")
 
 
 class MmeError(RuntimeError):
@@ -57,6 +57,8 @@ EXPORTS = {
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_cluster_pages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
@@ -262,6 +264,32 @@ class Engine:
                                                scores.data_ptr(), self._stream()), "mme_cluster_pages")
         sc = scores.cpu().numpy()
         return labels.cpu().numpy().tolist(), int(k.item()), [(i, float(sc[i])) for i in range(2, 16) if sc[i] == sc[i]]
+
+    def neighbours(self, emb_bf16, group=None, *, row0=0, nrows=None, fetch=30, top_n=10, keep_self=False,
+                   min_sim=-float("inf"), max_sim=float("inf")):
+        """Ranked neighbour lists of rows [row0, row0+nrows) of the normalised bf16 rows emb_bf16[N, d].
+
+        group: optional int32[N] (CUDA tensor or array); rows with the query's group id are dropped.
+        Returns (idx int32[nrows, top_n] padded with -1, sim float32[nrows, top_n]) CUDA tensors."""
+        t = self.torch
+        dev = t.device(f"cuda:{self.device}")
+        e = emb_bf16.contiguous()
+        if e.dtype != t.bfloat16 or e.dim() != 2 or e.device != dev:
+            raise MmeError("neighbours: emb must be a 2-D bfloat16 tensor on this engine's device")
+        N, d = e.shape
+        nrows = N - row0 if nrows is None else int(nrows)
+        g = None
+        if group is not None:
+            g = group if isinstance(group, t.Tensor) else t.from_numpy(np.ascontiguousarray(group, dtype=np.int32))
+            g = g.to(device=dev, dtype=t.int32).contiguous()
+            if g.numel() != N:
+                raise MmeError("neighbours: group must have one id per row")
+        idx = t.empty((max(nrows, 0), top_n), dtype=t.int32, device=dev)
+        sim = t.empty((max(nrows, 0), top_n), dtype=t.float32, device=dev)
+        self._check(self.lib.mme_neighbours(self.h, e.data_ptr(), N, d, g.data_ptr() if g is not None else None, int(row0), nrows,
+                                            int(fetch), int(top_n), int(bool(keep_self)), float(min_sim), float(max_sim),
+                                            idx.data_ptr(), sim.data_ptr(), self._stream()), "mme_neighbours")
+        return idx, sim
 
     def gemm_bench(self, M, N, K, epilogue=0, variant=0, iters=10):
         """(avg ms, TFLOP/s) for one GEMM shape on random data."""

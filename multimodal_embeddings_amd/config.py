@@ -24,3 +24,4 @@ DEFAULT_MODEL_NAME = "synthetic/vit-b16-224-seed1"  # stands in for config.py:58
 IMAGE_MEAN = (0.48145466, 0.4578275, 0.40821073)
 IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
 EMBED_DIM = 768
+WEIGHT_BY_AREA = True  # config.py:79

@@ -57,3 +57,47 @@ def cross_compare(vecs, other=None, *, engine: Engine | None = None, as_numpy: b
     b = a if other is None else to_unit_bf16(other, engine)
     sim = engine.cosine(a, b)
     return sim.cpu().numpy() if as_numpy else sim
+
+
+def image_neighbours(vecs, filenames, top_n=None, *, score="cosine", engine: Engine | None = None):
+    """Per image: its `top_n` most similar images with a different filename prefix.
+
+    Mirrors the query + filter loop of `create_cross_comparison`
+    (deprecated_package/cross_compare.py:109-235): fetch min(5*top_n, 100) nearest images (:117),
+    drop the source (:176) and every candidate whose filename starts with the SOURCE's first
+    max(1, int(len*0.2)) characters (:109-110, :200-206), keep the first top_n (:234).  The prefix
+    length depends on the source, so this rule is applied on the host to the kernel's raw ranked
+    list (K12 with keep_self).  `score="reference_distance"` reports the store's cosine distance,
+    which is what :210 prints as "similarity".
+    Returns a list (one per image) of [{"index", "filename", "prefix", "score"}, ...].
+    """
+    from . import config
+
+    top_n = config.CROSS_COMPARE_TOP_N if top_n is None else top_n
+    engine = engine or default_engine()
+    emb = to_unit_bf16(vecs, engine)
+    if emb.shape[0] != len(filenames):
+        raise ValueError("one filename per vector required")
+    fetch = min(top_n * 5, 100)
+    idx, sim = engine.neighbours(emb, None, fetch=fetch, top_n=fetch, keep_self=True)
+    idx, sim = idx.cpu().numpy(), sim.cpu().numpy()
+    out = []
+    for r, name in enumerate(filenames):
+        plen = max(1, int(len(name) * 0.2))
+        src_prefix = name[:plen]
+        lst = []
+        for c, s in zip(idx[r], sim[r]):
+            if c < 0:
+                break
+            if c == r:
+                continue
+            cand = filenames[c]
+            prefix = cand[:plen] if len(cand) >= plen else cand
+            if prefix == src_prefix:
+                continue
+            lst.append({"index": int(c), "filename": cand, "prefix": prefix,
+                        "score": float(s) if score == "cosine" else float(1.0 - s)})
+            if len(lst) >= top_n:
+                break
+        out.append(lst)
+    return out

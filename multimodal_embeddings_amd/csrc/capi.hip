@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -32,7 +33,7 @@ struct LayerDev {
     float *qkv_cs, *qkv_bf, *fc1_cs, *fc1_bf;
 };
 
-enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7 };
+enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7, KC_NEIGH = 8 };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -57,7 +58,7 @@ struct mme_ctx {
     float* lut = nullptr;  // [3,256]
     // workspace (sized for `chunk` crops)
     int ws_chunk = 0;
-    DevBuf x, hbuf, qkv, att, mlp, stats, patches, tmp, crops, hwork, page_ws, cluster_ws;
+    DevBuf x, hbuf, qkv, att, mlp, stats, patches, tmp, crops, hwork, page_ws, cluster_ws, neigh_ws;
     // host staging for crop tables
     std::vector<CropDesc> h_crops;
     std::vector<HWork> h_work;
@@ -425,7 +426,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->neigh_ws};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -664,6 +665,38 @@ int mme_cluster_pages(mme_ctx* c, const double* S, int P, int n_clusters, int mo
     Timed t(c, s, KC_CLUSTER);
     HIP_TRY(c, hipMemsetAsync(scores, 0xff, 16 * sizeof(double), s));  // NaN = "not evaluated"
     HIP_TRY(c, launch_cluster(S, P, n_clusters, mode, (char*)c->cluster_ws.p, labels, k_out, scores, s));
+    return MME_OK;
+}
+
+int mme_neighbours(mme_ctx* c, const uint16_t* emb, int N, int d, const int32_t* group, int row0, int nrows, int fetch, int top_n,
+                   int keep_self, float min_sim, float max_sim, int32_t* idx, float* sim, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (N < 0 || nrows < 0 || row0 < 0 || d <= 0 || (d % 64) != 0) return fail(c, MME_E_ARG, "mme_neighbours: bad sizes (N=%d nrows=%d d=%d)", N, nrows, d);
+    if (fetch < 1 || fetch > 128 || top_n < 1 || top_n > 128) return fail(c, MME_E_ARG, "mme_neighbours: fetch and top_n must be in 1..128");
+    if (nrows == 0) return MME_OK;
+    if ((int64_t)row0 + nrows > N) return fail(c, MME_E_ARG, "mme_neighbours: query rows [%d, %d) exceed N=%d", row0, row0 + nrows, N);
+    if (!emb || !idx || !sim) return fail(c, MME_E_ARG, "mme_neighbours: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // cosine block of a chunk of query rows: [rc, ldq] f32, at most 2 GiB (the top-k runs one wave per row and
+    // needs thousands of rows to fill the chip: 64 MiB chunks ran 6x slower), whole 256-row GEMM tiles
+    const int64_t ldq = ((int64_t)N + 3) & ~(int64_t)3;
+    static const int64_t ws_mb = getenv("MME_NEIGH_WS_MB") ? atoll(getenv("MME_NEIGH_WS_MB")) : 2048;
+    int64_t rc = (ws_mb << 20) / (ldq * 4);
+    rc = rc < 256 ? 256 : (rc / 256) * 256;
+    if (rc > nrows) rc = nrows;
+    int r;
+    if ((r = ensure(c, c->neigh_ws, (size_t)rc * ldq * 4))) return r;
+    float* qsim = (float*)c->neigh_ws.p;
+    Timed t(c, s, KC_NEIGH);
+    for (int64_t c0 = 0; c0 < nrows; c0 += rc) {
+        const int m = (int)(nrows - c0 < rc ? nrows - c0 : rc);
+        GemmArgs g{};
+        g.A = emb + (size_t)(row0 + c0) * d; g.W = emb; g.M = m; g.N = N; g.K = d; g.outf = qsim; g.ldf = ldq;
+        HIP_TRY(c, launch_gemm(EPI_F32, g, s, c->gemm_variant));
+        HIP_TRY(c, launch_topk_rows(qsim, ldq, N, m, (int)(row0 + c0), group, fetch, top_n, keep_self, min_sim, max_sim,
+                                    idx + (size_t)c0 * top_n, sim + (size_t)c0 * top_n, s));
+    }
     return MME_OK;
 }
 

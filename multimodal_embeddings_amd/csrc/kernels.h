@@ -86,6 +86,11 @@ struct PageSimArgs {
 };
 hipError_t launch_page_similarity(const PageSimArgs& a, hipStream_t s);
 
+// K12 ranked neighbour lists (neighbours.hip): one wave per row of qsim[nrows, ld] keeps the best `fetch`
+// entries in (similarity desc, index asc) order, then filters self / group / score window into top_n
+hipError_t launch_topk_rows(const float* qsim, int64_t ld, int N, int nrows, int row0, const int32_t* group, int fetch, int top_n,
+                            int keep_self, float min_sim, float max_sim, int32_t* idx_out, float* sim_out, hipStream_t s);
+
 // K11 page clustering (cluster.hip): labels_out int32[P], k_out int32[1], scores_out double[16]
 hipError_t launch_cluster(const double* S, int P, int n_clusters, int mode, char* ws, int32_t* labels_out, int32_t* k_out,
                           double* scores_out, hipStream_t s);

@@ -153,39 +153,81 @@ def compute_image_similarity_matrix(
 
 
 def neighbour_lists(
-    emb: np.ndarray,
-    group_of: np.ndarray,
+    emb: np.ndarray | None,
+    group_of: np.ndarray | None,
     *,
     top_n: int = 10,
     fetch: int | None = None,
     area_percentage: np.ndarray | None = None,
     metric: str = "cosine",
+    sim: np.ndarray | None = None,
+    rows: range | None = None,
+    keep_self: bool = False,
+    min_sim: float = -np.inf,
+    max_sim: float = np.inf,
 ):
-    """Ranking rule behind region_compare.py:160-353 (true-cosine form, see G2).
+    """Selection loop of region_compare.py:160-353.
 
-    Per row: take the `fetch` = min(3*top_n, 100) nearest rows (self included, as
-    chroma returns it), drop self (:244) and rows of the same parent page (:260),
-    keep the first `top_n`.  Returns (idx[N, top_n] int64 padded with -1,
-    sim[N, top_n] f64 cosine, weighted[N, top_n] = sim*a_src/100*a_tgt/100 (:273-278)).
+    Per query row r: take the `fetch` = min(3*top_n, 100) nearest rows (:163; r itself is among
+    them, as the store's query returns it) in stable ascending-distance order, drop r (:244), drop
+    rows of r's group = same parent page (:260), drop similarities outside [min_sim, max_sim]
+    (the score window of :269 -- G2: the reference applies it to the raw distance, i.e.
+    max_sim = 1 - 0.3), keep the first `top_n` (:352).  `sim` overrides the f64 cosine matrix (tests
+    pass the kernel's own f32 values so that ties break on identical numbers).
+    Returns (idx[R, top_n] int64 padded with -1, sim[R, top_n] f64 cosine, weighted[R, top_n] =
+    sim*a_src/100*a_tgt/100 (:273-278)).
     """
-    N = emb.shape[0]
+    C = cosine_matrix(emb) if sim is None else np.asarray(sim)
+    N = C.shape[1]
+    rows = range(N) if rows is None else rows
     fetch = min(3 * top_n, 100) if fetch is None else fetch
-    C = cosine_matrix(emb)
-    idx = np.full((N, top_n), -1, dtype=np.int64)
-    sim = np.zeros((N, top_n), dtype=np.float64)
-    wsim = np.zeros((N, top_n), dtype=np.float64)
-    for r in range(N):
-        d = 1.0 - C[r] if metric == "cosine" else 2.0 - 2.0 * C[r]
+    idx = np.full((len(rows), top_n), -1, dtype=np.int64)
+    out = np.zeros((len(rows), top_n), dtype=np.float64)
+    wsim = np.zeros((len(rows), top_n), dtype=np.float64)
+    for o, r in enumerate(rows):
+        row = C[o] if C.shape[0] == len(rows) and C.shape[0] != N else C[r]
+        d = 1.0 - row if metric == "cosine" else 2.0 - 2.0 * row
         order = np.argsort(d, kind="stable")[:fetch]
         k = 0
         for c in order:
-            if c == r or group_of[c] == group_of[r]:
+            if c == r and not keep_self:
                 continue
-            idx[r, k] = c
-            sim[r, k] = C[r, c]
+            if group_of is not None and c != r and group_of[c] == group_of[r]:
+                continue
+            if not (min_sim <= row[c] <= max_sim):
+                continue
+            idx[o, k] = c
+            out[o, k] = row[c]
             if area_percentage is not None:
-                wsim[r, k] = C[r, c] * (area_percentage[r] / 100.0) * (area_percentage[c] / 100.0)
+                wsim[o, k] = row[c] * (area_percentage[r] / 100.0) * (area_percentage[c] / 100.0)
             k += 1
             if k == top_n:
                 break
-    return idx, sim, wsim
+    return idx, out, wsim
+
+
+def image_neighbour_lists(sim: np.ndarray, filenames, *, top_n: int = 5, fetch: int | None = None):
+    """Selection loop of cross_compare.py:109-235: `fetch` = min(5*top_n, 100) nearest images (:117),
+    drop the source (:176) and every image whose filename starts with the SOURCE's prefix of
+    max(1, int(len*0.2)) characters (:109-110, :200-206), keep the first top_n (:234).
+    Returns a list (one per image) of [(index, similarity), ...]."""
+    sim = np.asarray(sim)
+    N = sim.shape[0]
+    fetch = min(5 * top_n, 100) if fetch is None else fetch
+    out = []
+    for r in range(N):
+        plen = max(1, int(len(filenames[r]) * 0.2))
+        src_prefix = filenames[r][:plen]
+        order = np.argsort(1.0 - sim[r], kind="stable")[:fetch]
+        lst = []
+        for c in order:
+            if c == r:
+                continue
+            cand = filenames[c]
+            if (cand[:plen] if len(cand) >= plen else cand) == src_prefix:
+                continue
+            lst.append((int(c), float(sim[r, c])))
+            if len(lst) == top_n:
+                break
+        out.append(lst)
+    return out

@@ -177,11 +177,127 @@ def unit_vectors(n, d, seed, clusters=0):
     return v.astype(np.float32)
 
 
+class StoreFake:
+    """Exact-kNN stand-in with the calls region_compare.py / cross_compare.py make: get(where),
+    get(ids), query (cosine space: distance = 1 - cos, ascending, stable)."""
+
+    def __init__(self, ids, emb, metas, docs):
+        self.ids, self.metas, self.docs = list(ids), list(metas), list(docs)
+        self.emb = np.asarray(emb, dtype=np.float64)
+        self.norm = self.emb / np.linalg.norm(self.emb, axis=1, keepdims=True)
+        self.pos = {i: k for k, i in enumerate(self.ids)}
+
+    def _rows(self, where):
+        if not where:
+            return list(range(len(self.ids)))
+        (key, cond), = where.items()
+        return [i for i, m in enumerate(self.metas) if m.get(key) == cond["$eq"]]
+
+    def get(self, ids=None, include=None, where=None):
+        rows = self._rows(where) if ids is None else [self.pos[i] for i in ids if i in self.pos]
+        return {"ids": [self.ids[r] for r in rows], "metadatas": [self.metas[r] for r in rows],
+                "embeddings": [self.emb[r].tolist() for r in rows], "documents": [self.docs[r] for r in rows]}
+
+    def query(self, query_embeddings, n_results, include=None, where=None):
+        q = np.asarray(query_embeddings[0], dtype=np.float64)
+        q = q / np.linalg.norm(q)
+        rows = np.array(self._rows(where), dtype=np.int64)
+        d = 1.0 - self.norm[rows] @ q
+        order = np.argsort(d, kind="stable")[:n_results]
+        return {"ids": [[self.ids[rows[k]] for k in order]], "distances": [[float(d[k]) for k in order]],
+                "metadatas": [[self.metas[rows[k]] for k in order]], "documents": [[self.docs[rows[k]] for k in order]]}
+
+
+def golden_neighbours():
+    """What create_region_cross_comparison (region_compare.py:25) and create_cross_comparison
+    (cross_compare.py:19) select, run on brute-force stores -> neighbour_cases.npz / .json."""
+    import cross_compare as cc
+    import region_compare as rc
+
+    out = {}
+    # -- regions: 9 pages, clustered 32-d vectors, exact duplicates, zero areas, a row without parent
+    rng = np.random.default_rng(41)
+    counts = [14, 3, 25, 11, 0, 1, 40, 12, 7]
+    ids, metas, docs, page = [], [], [], []
+    for p, c in enumerate(counts):
+        for r in range(c):
+            k = len(ids)
+            ap = float(np.exp(rng.uniform(np.log(1e-2), np.log(20.0)))) if rng.random() > 0.08 else 0.0
+            ids.append(f"region_p{p}_{r}")
+            metas.append({"parent_image": f"/data/pages/Paper {p:02d}.png", "region_type": ["plain_text", "title", "figure"][k % 3],
+                          "box_str": f"{k},0,{k + 1},1", "region_index": r, "area_percentage": ap, "is_region": True})
+            docs.append(f"Region: plain_text from Paper {p:02d}.png")
+            page.append(p)
+    emb = unit_vectors(len(ids), 32, 43, clusters=6)
+    emb[20] = emb[21]
+    emb[70] = emb[71] = emb[72]
+    emb[5] = emb[60]  # duplicates across pages: distance 0 < 0.3 -> dropped by the literal G2 rule
+    del metas[33]["box_str"]  # a source the reference skips (:147-149) but still returns as a candidate
+    store = StoreFake(ids, emb, metas, docs)
+    picked = {}
+
+    def record(parent_image, box, similar_parent, similar_box, score, vis_path):
+        picked.setdefault(int(box[0]), []).append((int(similar_box[0]) if similar_box[2] else 33, float(score)))
+
+    rc.create_region_comparison_visualization = record
+    rc.is_region_comparison_completed = lambda rid: False
+    rc.mark_region_comparison_as_completed = lambda rid: None
+    rc.load_region_comparison_progress = lambda: {"completed_comparisons": []}
+    rc.save_region_comparison_progress = lambda x: None
+    rc.tqdm = lambda it, **kw: it
+    assert rc.create_region_cross_comparison(store) is True
+    n, top = len(ids), rc.REGION_COMPARE_TOP_N
+    idx = np.full((n, top), -1, dtype=np.int64)
+    score = np.zeros((n, top))
+    for r, lst in picked.items():
+        for k, (c, sc) in enumerate(lst):
+            idx[r, k], score[r, k] = c, sc
+    out.update(region_emb=emb, region_page=np.array(page), region_area=np.array([m["area_percentage"] for m in metas]),
+               region_idx=idx, region_distance=score, region_no_box=np.array([33]))
+    print("region neighbour golden:", int((idx >= 0).sum()), "picks over", n, "regions")
+
+    # -- whole images: prefix rule of cross_compare.py:109-110,200-206
+    os.makedirs("imgs", exist_ok=True)
+    names = []
+    for t, title in enumerate(["Addison NY Advertiser 1883", "Addison NY Advertiser 1884", "Bath Plaindealer 1885", "Corning Journal"]):
+        for k in range(7 if t < 3 else 4):
+            names.append(f"{title} - {k:04d}.png")
+    names += ["a.png", "ab.png", "Short.png"]
+    paths = [os.path.join(os.getcwd(), "imgs", nm) for nm in names]
+    for pth in paths:
+        open(pth, "w").close()  # candidates must exist on disk (:188-191)
+    iemb = unit_vectors(len(names), 64, 47, clusters=4)
+    iemb[3] = iemb[9]
+    istore = StoreFake([f"image_{nm}" for nm in names], iemb, [{"image_path": pth} for pth in paths], [None] * len(names))
+    cc.is_cross_compare_completed = lambda pth: False
+    cc.mark_cross_compare_as_completed = lambda pth: None
+    cc.load_cross_compare_progress = lambda: {"completed_images": []}
+    cc.save_cross_compare_progress = lambda x: None
+    cc.create_cross_comparison(None, istore, paths)
+    top = cc.CROSS_COMPARE_TOP_N
+    iidx = np.full((len(names), top), -1, dtype=np.int64)
+    iscore = np.zeros((len(names), top))
+    for r, nm in enumerate(names):
+        stem = os.path.splitext(nm)[0].replace(" ", "_").replace(".", "_")
+        page_html = open(os.path.join(cc.CROSS_COMPARE_FOLDER, "html_pages", stem + ".html")).read()
+        hits = re.findall(r"<p><strong>(\d+)\.</strong> (.*?)</p>.*?Similarity score: <span class=\"score\">([0-9.\-]+)</span>", page_html, re.S)
+        for k, (_, fname, sc) in enumerate(hits):
+            iidx[r, k], iscore[r, k] = names.index(html.unescape(fname)), float(sc)
+    out.update(image_emb=iemb, image_idx=iidx, image_distance_4dp=iscore)
+    json.dump({"image_names": names}, open(os.path.join(HERE, "neighbour_names.json"), "w"))
+    np.savez_compressed(os.path.join(HERE, "neighbour_cases.npz"), **out)
+    print("image neighbour golden:", int((iidx >= 0).sum()), "picks over", len(names), "images")
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix="golden_")
     os.chdir(scratch)
     os.makedirs("output", exist_ok=True)
     w, ref_embedder = import_reference()
+    if "--only-neighbours" in sys.argv:
+        golden_neighbours()
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
     import torch
 
     # ---- 1. report KAT -------------------------------------------------------------
@@ -310,6 +426,7 @@ def main():
         pc[f"syn_S_{metric}"] = S
     np.savez_compressed(os.path.join(HERE, "pagesim_cases.npz"), **pc)
     print("pagesim cases ok")
+    golden_neighbours()
 
     # ---- 5. last_pooling -------------------------------------------------------------
     g = torch.Generator().manual_seed(3)

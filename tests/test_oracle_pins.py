@@ -185,3 +185,43 @@ def test_bundled_crop_sizes_equal_int_bbox(golden_dir):
             assert Image.open(f).size == (x1 - x0, y1 - y0)
             checked += 1
     assert checked == 1862
+
+
+def test_neighbour_lists_match_reference_region_report(golden_dir):
+    """oracle.neighbour_lists == what create_region_cross_comparison (region_compare.py:25) picked on a
+    brute-force store: ranks, same-page / self drops, the literal distance >= 0.3 window (G2)."""
+    from oracle import compare as oc
+
+    g = np.load(os.path.join(golden_dir, "neighbour_cases.npz"))
+    emb, page, area = g["region_emb"], g["region_page"], g["region_area"]
+    idx, sim, w = oc.neighbour_lists(emb, page, top_n=10, area_percentage=area, max_sim=1.0 - 0.3)
+    want_idx, want_d = g["region_idx"].copy(), g["region_distance"]
+    no_box = int(g["region_no_box"][0])
+    assert (want_idx[no_box] == -1).all()  # the reference skips it as a source (:147-149)
+    rows = [r for r in range(len(emb)) if r != no_box]
+    assert np.array_equal(idx[rows], want_idx[rows])
+    got_d = np.where(idx >= 0, 1.0 - sim, 0.0)
+    assert np.abs(got_d[rows] - want_d[rows]).max() < 1e-12
+    # every picked distance is >= 0.3 although nearer neighbours exist: the inverted threshold of G2
+    assert want_d[want_idx >= 0].min() >= 0.3 and (1.0 - oc.cosine_matrix(emb)[5, 60]) < 1e-12 and 60 not in want_idx[5]
+    # weighted score of :273-278 (on the similarity here; the reference multiplies its distance)
+    r, c = rows[0], idx[rows[0], 0]
+    assert w[r, 0] == sim[r, 0] * (area[r] / 100.0) * (area[c] / 100.0)
+
+
+def test_image_neighbour_lists_match_reference_cross_compare(golden_dir):
+    """oracle.image_neighbour_lists == the picks create_cross_comparison (cross_compare.py:19) wrote
+    into its HTML pages (source-dependent 20 % filename prefix rule), scores at the 4 printed decimals."""
+    from oracle import compare as oc
+
+    g = np.load(os.path.join(golden_dir, "neighbour_cases.npz"))
+    names = json.load(open(os.path.join(golden_dir, "neighbour_names.json")))["image_names"]
+    lists = oc.image_neighbour_lists(oc.cosine_matrix(g["image_emb"]), names, top_n=5)
+    want_idx, want_d = g["image_idx"], g["image_distance_4dp"]
+    for r, lst in enumerate(lists):
+        k = len(lst)
+        assert [c for c, _ in lst] == want_idx[r, :k].tolist() and (want_idx[r, k:] == -1).all(), r
+        assert all(abs(round(1.0 - s, 4) - want_d[r, j]) < 1e-9 for j, (_, s) in enumerate(lst))
+    assert all(len(l) == 5 for l in lists)
+    # the 7-character prefix of an 'Addison NY Advertiser 1883' page excludes the 1884 pages too
+    assert all(not names[c].startswith("Addison") for c, _ in lists[0])
