@@ -96,6 +96,19 @@ int mme_set_gemm_variant(mme_ctx* ctx, int variant);
  * LayerNorm and no normalised copy is written.  0 = separate LayerNorm kernel (A/B, tests). */
 int mme_set_ln_fusion(mme_ctx* ctx, int on);
 
+/* ---- K0: cut the bounding boxes of one decoded page on the device ----------
+ * Replaces DocLayoutDetector.get_region_image (doclayout_detector.py:165-194), which re-opens
+ * and re-decodes the whole page PNG for every region: the page is uploaded once and every box
+ * is gathered into the packed crop buffer that mme_preprocess / mme_embed read.
+ *   page_dev    uint8 RGB HWC pixels of the page, [H, W, 3]
+ *   boxes_host  int32[n,4] (x0, y0, x1, y1) AFTER the reference's int() truncation
+ *               (doclayout_detector.py:179); crop i is (y1-y0) x (x1-x0) pixels; parts of a box
+ *               outside the page read as 0, as PIL's Image.crop fills them
+ *   pix_dev     destination buffer; offs_host int64[n] byte offset of crop i in it (same
+ *               packing rule as mme_preprocess: 16-byte aligned crops, 16 bytes of slack) */
+int mme_crop_boxes(mme_ctx* ctx, const uint8_t* page_dev, int H, int W, const int32_t* boxes_host, int n, uint8_t* pix_dev,
+                   const int64_t* offs_host, void* stream);
+
 /* ---- K1: crop -> resize -> pad -> normalise -> patchify ------------------------------
  * Replaces, per crop, `processor(images=[image])` (embedder.py:117-121; transformers
  * image_processing_pil_mllama.py:483-541 with tile 224, one tile): aspect-preserving

@@ -57,6 +57,7 @@ EXPORTS = {
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_cluster_pages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_crop_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
@@ -186,6 +187,28 @@ class Engine:
         if len(offs) != len(hw):
             raise ValueError("offs and hw disagree")
         return offs, hw
+
+    def crop_boxes(self, page, boxes):
+        """page: uint8 CUDA tensor [H, W, 3]; boxes: int array [n, 4] (x0, y0, x1, y1), already int()-truncated.
+
+        Returns (pix uint8 CUDA tensor, offs int64[n], hw int32[n, 2]) ready for `preprocess` / `embed`."""
+        t = self.torch
+        if page.dtype != t.uint8 or page.dim() != 3 or page.shape[2] != 3 or not page.is_contiguous():
+            raise MmeError("crop_boxes: page must be a contiguous uint8 [H, W, 3] tensor")
+        b = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 4))
+        n = len(b)
+        hw = np.ascontiguousarray(np.stack([b[:, 3] - b[:, 1], b[:, 2] - b[:, 0]], axis=1).astype(np.int32)) if n else np.zeros((0, 2), np.int32)
+        if n and (hw.min() <= 0 or hw.max() > 8000):
+            raise MmeError("crop_boxes: every box must be 1..8000 pixels wide and high after int() truncation")
+        size = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+        offs = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            offs[1:] = np.cumsum((size[:-1] + 15) // 16 * 16)
+        total = int(offs[-1] + size[-1]) if n else 0
+        pix = t.empty(total + 16, dtype=t.uint8, device=page.device)
+        self._check(self.lib.mme_crop_boxes(self.h, page.data_ptr(), int(page.shape[0]), int(page.shape[1]), b.ctypes.data, n,
+                                            pix.data_ptr(), offs.ctypes.data, self._stream()), "mme_crop_boxes")
+        return pix, offs, hw
 
     def preprocess(self, pix, offs, hw):
         """pix: uint8 CUDA tensor (concatenated HWC crops, >=16 spare bytes at the end)."""

@@ -668,6 +668,37 @@ int mme_cluster_pages(mme_ctx* c, const double* S, int P, int n_clusters, int mo
     return MME_OK;
 }
 
+int mme_crop_boxes(mme_ctx* c, const uint8_t* page, int H, int W, const int32_t* boxes, int n, uint8_t* pix, const int64_t* offs,
+                   void* stream) {
+    if (!c) return MME_E_ARG;
+    if (n < 0 || H <= 0 || W <= 0) return fail(c, MME_E_ARG, "mme_crop_boxes: bad sizes (n=%d, page %dx%d)", n, H, W);
+    if (n == 0) return MME_OK;
+    if (!page || !boxes || !pix || !offs) return fail(c, MME_E_ARG, "mme_crop_boxes: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    c->h_work.clear();
+    for (int i = 0; i < n; ++i) {
+        const int w = boxes[4 * i + 2] - boxes[4 * i], h = boxes[4 * i + 3] - boxes[4 * i + 1];
+        if (w <= 0 || h <= 0 || w > 8000 || h > 8000)
+            return fail(c, MME_E_ARG, "mme_crop_boxes: box %d is %dx%d (w x h); supported 1..8000", i, w, h);
+        int rows = (32 * 1024) / (w * 3);
+        rows = rows < 1 ? 1 : rows;
+        for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
+    }
+    int r;
+    const size_t bbytes = (size_t)n * 4 * sizeof(int32_t), obytes = (size_t)n * sizeof(int64_t);
+    if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
+    if ((r = ensure(c, c->crops, bbytes + obytes + 16))) return r;
+    char* meta = (char*)c->crops.p;  // offs (8-byte aligned) | boxes
+    HIP_TRY(c, hipMemcpyAsync(meta, offs, obytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(meta + obytes, boxes, bbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
+    Timed t(c, s, KC_PRE);
+    HIP_TRY(c, launch_crop_boxes(page, H, W, (const int32_t*)(meta + obytes), (const int64_t*)meta, (const HWork*)c->hwork.p,
+                                 (int)c->h_work.size(), pix, s));
+    return MME_OK;
+}
+
 int mme_neighbours(mme_ctx* c, const uint16_t* emb, int N, int d, const int32_t* group, int row0, int nrows, int fetch, int top_n,
                    int keep_self, float min_sim, float max_sim, int32_t* idx, float* sim, void* stream) {
     if (!c) return MME_E_ARG;

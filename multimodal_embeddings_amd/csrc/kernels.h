@@ -59,6 +59,9 @@ struct HWork {  // one block of the horizontal pass: a band of source rows of on
 };
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
                            int band_bytes, hipStream_t s);
+// K0: boxes int32[n,4] (x0,y0,x1,y1), offs int64[n] byte offsets into pix; zero fill outside the page
+hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* boxes, const int64_t* offs, const HWork* work, int nwork,
+                             uint8_t* pix, hipStream_t s);
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
                                     const float* lut /*[3,256]*/, void* patches, bool any_resize, hipStream_t s);
 

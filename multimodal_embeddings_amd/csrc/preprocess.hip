@@ -197,7 +197,37 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
     }
 }
 
+// K0: cut every bounding box of ONE decoded page into the packed crop buffer K1 reads.
+// Restates DocLayoutDetector.get_region_image (doclayout_detector.py:178-189): the box corners
+// are already int()-truncated by the caller; `image.crop` keeps the box size and fills what
+// lies outside the page with zeros.  One work item = a run of rows of one box (~32 KiB), a
+// plain byte gather: HBM bound, 2 x box bytes.
+__global__ __launch_bounds__(256) void crop_boxes(const uint8_t* __restrict__ page, int H, int W, const int32_t* __restrict__ boxes,
+                                                  const int64_t* __restrict__ offs, const HWork* __restrict__ work,
+                                                  uint8_t* __restrict__ pix) {
+    const HWork wk = work[blockIdx.x];
+    const int x0 = boxes[4 * wk.crop], y0 = boxes[4 * wk.crop + 1], x1 = boxes[4 * wk.crop + 2];
+    const int row_bytes = (x1 - x0) * 3;
+    uint8_t* dst = pix + offs[wk.crop] + (int64_t)wk.row0 * row_bytes;
+    const int total = wk.nrows * row_bytes;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int r = e / row_bytes, b = e - r * row_bytes;
+        const int y = y0 + wk.row0 + r;
+        const int xb = x0 * 3 + b;  // byte column inside the page row
+        uint8_t v = 0;
+        if (y >= 0 && y < H && xb >= 0 && xb < W * 3) v = page[((int64_t)y * W) * 3 + xb];
+        dst[e] = v;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* boxes, const int64_t* offs, const HWork* work, int nwork,
+                             uint8_t* pix, hipStream_t s) {
+    if (nwork <= 0) return hipSuccess;
+    hipLaunchKernelGGL(crop_boxes, dim3(nwork), dim3(256), 0, s, page, H, W, boxes, offs, work, pix);
+    return hipGetLastError();
+}
 
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
                            int band_bytes, hipStream_t s) {

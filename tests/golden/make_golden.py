@@ -289,13 +289,66 @@ def golden_neighbours():
     print("image neighbour golden:", int((iidx >= 0).sum()), "picks over", len(names), "images")
 
 
+def golden_regions():
+    """RegionProcessor.process_image_regions (region_processor.py:62) + the real
+    DocLayoutDetector.get_region_image (doclayout_detector.py:165) on a seeded page -> region_rows.json:
+    ids, metadata rows, documents and the sha256 of every crop the embedder was handed."""
+    from PIL import Image
+
+    for n in ["doclayout_yolo", "ultralytics"]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["doclayout_yolo"].YOLOv10 = object
+    import region_processor as rp
+    from doclayout_detector import DocLayoutDetector
+
+    seed, H, W = 77, 220, 300
+    page = np.random.default_rng(seed).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    os.makedirs("pages", exist_ok=True)
+    page_path = os.path.join(os.getcwd(), "pages", "Seeded Gazette 1901 - 0007.png")
+    Image.fromarray(page).save(page_path)
+    regions = {
+        "boxes": [[10.7, 20.2, 99.9, 80.5], [0.0, 0.0, 300.0, 220.0], [150.2, 5.9, 299.99, 40.1], [-3.6, 100.4, 40.2, 130.9],
+                  [250.5, 180.3, 320.7, 240.2], [30.0, 30.0, 31.9, 200.0], [5.5, 210.1, 295.5, 219.9], [60.0, 60.0, 120.0, 90.0]],
+        "classes": [1, 0, 3, 1, 5, 1, 4, 2],
+        "class_names": ["plain_text", "title", "figure", "plain_text", "table", "plain_text", "figure_caption", "abandon"],
+        "scores": [0.91, 0.88, 0.75, 0.66, 0.5, 0.41, 0.33, 0.2],
+        "image_size": {"width": W, "height": H},
+    }
+    crops, upserts = [], []
+
+    class Emb:
+        def get_image_embeddings(self, paths):
+            for pth in paths:
+                crops.append(np.array(Image.open(pth).convert("RGB")))  # embedder.py:107
+            return [[float(k)] * 4 for k in range(len(paths))]
+
+    class Col:
+        def upsert(self, ids, embeddings, documents, metadatas):
+            upserts.append((ids, documents, metadatas))
+
+    det = types.SimpleNamespace(get_region_image=lambda pth, box, padding=0: DocLayoutDetector.get_region_image(None, pth, box, padding))
+    rp.is_region_embedding_completed = lambda rid: False
+    rp.mark_region_embedding_as_completed = lambda rid: None
+    count = rp.RegionProcessor(Emb(), Col(), det).process_image_regions(page_path, regions)
+    ids = [i for u in upserts for i in u[0]]
+    docs = [d for u in upserts for d in u[1]]
+    metas = [dict(m, parent_image="<page_path>") for u in upserts for m in u[2]]
+    assert count == len(ids) == len(crops)
+    json.dump({"seed": seed, "page_hw": [H, W], "page_name": os.path.basename(page_path), "regions": regions, "ids": ids,
+               "documents": docs, "metadatas": metas, "crop_shapes": [list(c.shape) for c in crops],
+               "crop_sha256": [hashlib.sha256(np.ascontiguousarray(c).tobytes()).hexdigest() for c in crops]},
+              open(os.path.join(HERE, "region_rows.json"), "w"), indent=1)
+    print("region rows golden:", count, "regions;", [c.shape for c in crops])
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix="golden_")
     os.chdir(scratch)
     os.makedirs("output", exist_ok=True)
     w, ref_embedder = import_reference()
-    if "--only-neighbours" in sys.argv:
+    if "--only-next" in sys.argv:  # the SURVEY 8(f) rows only (leaves the other fixtures untouched)
         golden_neighbours()
+        golden_regions()
         shutil.rmtree(scratch, ignore_errors=True)
         return
     import torch
@@ -427,6 +480,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "pagesim_cases.npz"), **pc)
     print("pagesim cases ok")
     golden_neighbours()
+    golden_regions()
 
     # ---- 5. last_pooling -------------------------------------------------------------
     g = torch.Generator().manual_seed(3)

@@ -1,0 +1,109 @@
+"""K0 crop-from-page (mme_crop_boxes) and the RegionProcessor mirror, against the reference's own rows /
+crops (tests/golden/region_rows.json) and PIL's Image.crop on real page geometry."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def embedder():
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+
+    return RegionEmbedder()
+
+
+def _unpack(pix, offs, hw):
+    host = pix.cpu().numpy()
+    return [host[o : o + h * w * 3].reshape(h, w, 3) for o, (h, w) in zip(offs, hw)]
+
+
+def test_crop_boxes_reproduces_reference_crops(embedder, golden_dir):
+    from multimodal_embeddings_amd.region_processor import region_rows
+
+    g = json.load(open(os.path.join(golden_dir, "region_rows.json")))
+    H, W = g["page_hw"]
+    page = np.random.default_rng(g["seed"]).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    _, _, boxes = region_rows(g["page_name"], g["regions"])
+    pix, offs, hw = embedder.engine.crop_boxes(torch.from_numpy(page).cuda(), boxes)
+    torch.cuda.synchronize()
+    assert (offs % 16 == 0).all() and pix.numel() >= offs[-1] + hw[-1, 0] * hw[-1, 1] * 3 + 16
+    for crop, shape, sha in zip(_unpack(pix, offs, hw), g["crop_shapes"], g["crop_sha256"]):
+        assert list(crop.shape) == shape and hashlib.sha256(np.ascontiguousarray(crop).tobytes()).hexdigest() == sha
+
+
+def test_crop_boxes_on_real_page_geometry_equals_pil(embedder, golden_dir):
+    """Every embeddable box of two bundled pages (3.4-7.9k px wide, ~100 boxes each) on seeded pixels: the
+    device gather equals PIL's crop byte for byte, and K1 on the gathered buffer equals K1 on PIL's crops."""
+    from PIL import Image
+
+    from multimodal_embeddings_amd.region_processor import region_rows
+
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    eng = embedder.engine
+    for p in (pages[0], pages[7], pages[12]):  # 7934 x 5755 with 5 boxes; 85 and 220 boxes
+        H, W = p["height"], p["width"]
+        page = np.random.default_rng(H + W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+        regions = {k: p[k] for k in ("boxes", "classes", "class_names", "scores")}
+        regions["image_size"] = {"width": W, "height": H}
+        ids, metas, boxes = region_rows(p["name"], regions)
+        assert len(ids) >= 1
+        pix, offs, hw = eng.crop_boxes(torch.from_numpy(page).cuda(), boxes)
+        img = Image.fromarray(page)
+        want = [np.array(img.crop(tuple(int(v) for v in b))) for b in boxes]
+        for got, w_ in zip(_unpack(pix, offs, hw), want):
+            assert np.array_equal(got, w_)
+        pix2, offs2, hw2 = embedder.pack(want)
+        assert np.array_equal(offs, offs2) and np.array_equal(hw, hw2)
+        assert torch.equal(eng.preprocess(pix, offs, hw), eng.preprocess(pix2, offs2, hw2))
+
+
+def test_crop_boxes_rejects_bad_boxes(embedder):
+    from multimodal_embeddings_amd._lib import MmeError
+
+    page = torch.zeros((50, 60, 3), dtype=torch.uint8, device="cuda")
+    for bad in ([[5, 5, 5, 20]], [[10, 30, 40, 20]], [[0, 0, 9000, 10]]):
+        with pytest.raises(MmeError):
+            embedder.engine.crop_boxes(page, bad)
+    pix, offs, hw = embedder.engine.crop_boxes(page, np.zeros((0, 4), np.int32))
+    assert len(offs) == 0 and hw.shape == (0, 2)
+
+
+def test_region_processor_upserts_reference_rows(embedder, golden_dir, tmp_path):
+    """process_image_regions(page, regions): same ids / metadata / documents as the reference upserted, and each
+    vector equals embedding that crop on its own through get_image_embeddings."""
+    from PIL import Image
+
+    from multimodal_embeddings_amd.region_processor import RegionProcessor
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection
+    from oracle import regions as oreg
+
+    g = json.load(open(os.path.join(golden_dir, "region_rows.json")))
+    H, W = g["page_hw"]
+    page = np.random.default_rng(g["seed"]).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    page_path = str(tmp_path / g["page_name"])
+    Image.fromarray(page).save(page_path)
+    col = RegionCollection()
+    rp = RegionProcessor(embedder, col)
+    assert rp.process_image_regions(page_path, g["regions"]) == 7
+    got = col.get(include=["metadatas", "embeddings", "documents"], where={"is_region": {"$eq": True}})
+    assert got["ids"] == g["ids"] and got["documents"] == g["documents"]
+    assert [dict(m, parent_image="<page_path>") for m in got["metadatas"]] == g["metadatas"]
+    kept = [b for b, c in zip(g["regions"]["boxes"], g["regions"]["class_names"]) if c in oreg.REGION_TYPES_TO_PROCESS]
+    alone = embedder.get_image_embeddings([oreg.crop_region(page, b) for b in kept])
+    assert np.array_equal(np.asarray(got["embeddings"], dtype=np.float32), np.asarray(alone, dtype=np.float32))
+    # empty / foreign-class inputs
+    assert rp.process_image_regions(page_path, {"boxes": []}) == 0
+    assert rp.process_image_regions(page_path, dict(g["regions"], class_names=["abandon"] * 8)) == 0
+    # a decoded page may be passed instead of the path; degenerate boxes are skipped like the reference's failed crops
+    col2 = RegionCollection()
+    regs = dict(g["regions"])
+    regs["boxes"] = [list(b) for b in regs["boxes"]]
+    regs["boxes"][0] = [10.2, 20.0, 10.9, 80.0]  # int() -> zero width
+    assert RegionProcessor(embedder, col2).process_image_regions(page_path, regs, page=page) == 6
+    assert col2.get()["ids"] == g["ids"][1:]

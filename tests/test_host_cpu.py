@@ -230,3 +230,24 @@ def test_graft_entry_build():
     import __graft_entry__ as g
 
     g.build()
+
+
+def test_region_rows_mirror_matches_reference_rows(golden_dir):
+    """multimodal_embeddings_amd.region_processor.region_rows == the rows the reference's RegionProcessor upserted."""
+    import json
+
+    from multimodal_embeddings_amd.region_processor import load_region_cache, region_rows
+
+    g = json.load(open(os.path.join(golden_dir, "region_rows.json")))
+    ids, metas, boxes = region_rows("<page_path>/" + g["page_name"], g["regions"])
+    assert ids == g["ids"]
+    assert [dict(m, parent_image="<page_path>") for m in metas] == g["metadatas"]
+    assert boxes.dtype == np.int32 and boxes.tolist()[3] == [-3, 100, 40, 130]  # int() truncates toward zero
+    assert [[int(b[3] - b[1]), int(b[2] - b[0]), 3] for b in boxes] == g["crop_shapes"]
+    # cache schema of doclayout_detector.py:145-153
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        pth = os.path.join(d, "x_conf0.1_iou0.45.json")
+        json.dump(g["regions"], open(pth, "w"))
+        assert load_region_cache(pth)["image_size"] == {"width": 300, "height": 220}

@@ -225,3 +225,23 @@ def test_image_neighbour_lists_match_reference_cross_compare(golden_dir):
     assert all(len(l) == 5 for l in lists)
     # the 7-character prefix of an 'Addison NY Advertiser 1883' page excludes the 1884 pages too
     assert all(not names[c].startswith("Addison") for c, _ in lists[0])
+
+
+def test_region_rows_and_crops_match_reference_region_processor(golden_dir):
+    """oracle.regions == what RegionProcessor.process_image_regions (region_processor.py:62) upserted and the
+    crops the real get_region_image (doclayout_detector.py:165) handed to the embedder -- fractional, edge
+    and partly-outside boxes, one class that is not embedded."""
+    from oracle import regions as oreg
+
+    g = json.load(open(os.path.join(golden_dir, "region_rows.json")))
+    H, W = g["page_hw"]
+    page = np.random.default_rng(g["seed"]).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    ids, metas, docs = oreg.region_rows("<page_path>/" + g["page_name"], g["regions"])
+    assert ids == g["ids"] and docs == g["documents"] and len(ids) == 7
+    for got, want in zip(metas, g["metadatas"]):
+        got = dict(got, parent_image="<page_path>")
+        assert got == want  # every key, floats bit-equal (area_percentage, box_normalized strings)
+    kept = [b for b, c in zip(g["regions"]["boxes"], g["regions"]["class_names"]) if c in oreg.REGION_TYPES_TO_PROCESS]
+    for box, shape, sha in zip(kept, g["crop_shapes"], g["crop_sha256"]):
+        crop = oreg.crop_region(page, box)
+        assert list(crop.shape) == shape and hashlib.sha256(crop.tobytes()).hexdigest() == sha
