@@ -179,3 +179,38 @@ def test_c5_page_matrix_properties_at_full_size(embedder):
         terms = ocmp.pair_terms(None, area, reg_i, rows_j, int(valid[rows_j].sum()), sim=_Sim())
         want = float(np.sum(terms)) if terms else 0.0
         assert Sraw[i, j] == pytest.approx(want, rel=1e-13, abs=1e-18), (i, j)
+
+
+def test_weighted_clustering_run_writes_reference_artefacts(embedder, golden_dir, tmp_path):
+    """run_weighted_clustering = body of wrc.main (:857-892) on the bundled 19-page / 1867-region table with the
+    seeded vectors of the pagesim golden: files named and encoded like the reference's, contents consistent
+    with the in-memory results, S close to the reference's f64 matrix."""
+    from multimodal_embeddings_amd.store import load_collection, run_weighted_clustering, save_collection
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection
+    from oracle import cluster as oc
+    from oracle.compare import REGION_TYPES_TO_PROCESS
+
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    g = np.load(os.path.join(golden_dir, "pagesim_cases.npz"))
+    emb, area, page_of = g["real_emb"], g["real_area_percentage"], g["real_page_of"]
+    names = [p["name"] for p in pages]
+    types = [c for p in pages for c in p["class_names"] if c in REGION_TYPES_TO_PROCESS]
+    assert len(types) == len(emb) == 1867
+    col = RegionCollection()
+    col.upsert(ids=[f"region_{i}" for i in range(len(emb))], embeddings=emb.tolist(),
+               metadatas=[{"parent_image_name": names[page_of[i]], "region_type": types[i], "area_percentage": float(area[i]), "is_region": True}
+                          for i in range(len(emb))])
+    save_collection(col, str(tmp_path / "regions"))
+    col = load_collection(str(tmp_path / "regions"))  # the stage boundary: rows come back from disk
+    out = run_weighted_clustering(col, ["/pages/" + n for n in names], str(tmp_path / "weighted"), engine=embedder.engine)
+    assert out is not None
+    S, nm, res = out
+    assert nm == names and np.array_equal(np.load(tmp_path / "weighted" / "similarity_matrix.npy"), S)
+    assert json.load(open(tmp_path / "weighted" / "image_names.json")) == names
+    saved = json.load(open(tmp_path / "weighted" / "clustering_results.json"))
+    assert saved["labels"] == res["labels"] and saved["n_clusters"] == res["n_clusters"] and saved["clusters"] == res["clusters"]
+    assert np.corrcoef(S.ravel(), g["real_S_cosine"].ravel())[0, 1] > 0.995  # bf16 rows vs the f64 reference, as in test_gpu_parity
+    want = oc.cluster_images(S.copy(), names)
+    assert res["labels"] == want["labels"]
+    empty = RegionCollection()
+    assert run_weighted_clustering(empty, ["/pages/" + n for n in names], str(tmp_path / "none"), engine=embedder.engine) is None

@@ -251,3 +251,43 @@ def test_region_rows_mirror_matches_reference_rows(golden_dir):
         pth = os.path.join(d, "x_conf0.1_iou0.45.json")
         json.dump(g["regions"], open(pth, "w"))
         assert load_region_cache(pth)["image_size"] == {"width": 300, "height": 220}
+
+
+def test_store_round_trip_and_progress_log(tmp_path):
+    """Region rows survive save/load in order and value; the resume log is idempotent, append-only and
+    reads the reference's `{"completed_...": [...]}` progress files."""
+    import json
+
+    from multimodal_embeddings_amd.store import ProgressLog, load_collection, save_clustering_outputs, save_collection
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection
+
+    rng = np.random.default_rng(0)
+    col = RegionCollection()
+    ids = [f"region_p{i // 3}_{i}" for i in range(7)]
+    metas = [{"parent_image_name": f"p{i // 3}.png", "region_type": "title", "area_percentage": float(i), "is_region": True} for i in range(7)]
+    emb = rng.standard_normal((7, 8)).astype(np.float32)
+    col.upsert(ids=ids, embeddings=emb.tolist(), documents=[f"Region: title from p{i // 3}.png" for i in range(7)], metadatas=metas)
+    assert save_collection(col, str(tmp_path / "db" / "regions")) == 7
+    back = load_collection(str(tmp_path / "db" / "regions")).get(include=["metadatas", "embeddings", "documents"])
+    assert back["ids"] == ids and back["metadatas"] == metas and back["documents"][0] == "Region: title from p0.png"
+    assert np.array_equal(np.asarray(back["embeddings"], dtype=np.float32), emb)
+
+    S = np.array([[1.0, 0.25], [0.25, 1.0]])
+    res = {"n_clusters": 2, "clusters": {"0": ["a.png"], "1": ["b.png"]}, "cluster_cohesion": {0: 0.0, 1: 0.0}, "labels": [0, 1]}
+    save_clustering_outputs(str(tmp_path / "out"), S, ["a.png", "b.png"], res)
+    assert np.array_equal(np.load(tmp_path / "out" / "similarity_matrix.npy"), S)
+    assert json.load(open(tmp_path / "out" / "image_names.json")) == ["a.png", "b.png"]
+    saved = json.load(open(tmp_path / "out" / "clustering_results.json"))
+    assert saved["cluster_cohesion"] == {"0": 0.0, "1": 0.0} and saved["labels"] == [0, 1]  # int keys -> strings, as wrc:888-889 writes
+
+    log = ProgressLog(str(tmp_path / "progress" / "regions.jsonl"))
+    assert not log.done("region_a")
+    log.mark("region_a")
+    log.mark("region_a")
+    log.mark("region_b")
+    assert open(log.path).read().count("\n") == 2  # one line per item, no rewrites
+    ref = tmp_path / "region_embedding_progress.json"
+    json.dump({"completed_regions": ["region_b", "region_c"]}, open(ref, "w"))
+    log.import_reference(str(ref), "completed_regions")
+    again = ProgressLog(log.path)
+    assert len(again) == 3 and again.done("region_c") and not again.done("region_d")
