@@ -47,11 +47,15 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and local >= torch.cuda.device_count():
+        # more ranks than GPUs (a rehearsal on a smaller box): share devices round-robin; RCCL cannot
+        # do that, so such a run needs MME_DIST_BACKEND=gloo
+        local %= torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MME_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
