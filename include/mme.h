@@ -207,6 +207,14 @@ int mme_neighbours(mme_ctx* ctx, const uint16_t* emb_dev, int N, int d, const in
  * variant as mme_set_gemm_variant. */
 int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms);
 
+/* Diagnostic: run the stamped build of the 256x256 3-deep-ring GEMM (bias epilogue) once on random data.
+ * stamps_host uint64[256 workgroups][2 waves (0 and 4)][16]: s_memtime cycles summed over the K-tiles the
+ * wave processed -- [0..7] the eight barrier-to-barrier intervals of a K-tile, [8] time in the counted wait,
+ * [9] everything between two tiles' K loops, [10] K-tiles processed, [11] of [9]: group sync + next tile's
+ * prologue issue, [12] of [9]: epilogue body (loads, math, store issue); the rest of [9] is the wait for the
+ * next tile's first K-tile. */
+int mme_gemm_stamps(mme_ctx* ctx, int M, int N, int K, uint64_t* stamps_host);
+
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
  * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster,
  * 8 neighbours */

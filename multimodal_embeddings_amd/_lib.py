@@ -61,6 +61,7 @@ EXPORTS = {
     "mme_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "mme_gemm_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
     "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -319,6 +320,12 @@ class Engine:
         ms = C.c_double(0)
         self._check(self.lib.mme_gemm_bench(self.h, M, N, K, epilogue, variant, iters, C.byref(ms)), "mme_gemm_bench")
         return ms.value, 2.0 * M * N * K / (ms.value * 1e-3) / 1e12
+
+    def gemm_stamps(self, M, N, K):
+        """uint64[256, 2, 16] in-kernel cycle stamps of the stamped GEMM build (see mme.h)."""
+        st = np.zeros((256, 2, 16), dtype=np.uint64)
+        self._check(self.lib.mme_gemm_stamps(self.h, M, N, K, st.ctypes.data), "mme_gemm_stamps")
+        return st
 
     # ---- timing ------------------------------------------------------------------------------------
     def profile(self, on: bool):

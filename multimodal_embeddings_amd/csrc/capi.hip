@@ -731,13 +731,14 @@ int mme_neighbours(mme_ctx* c, const uint16_t* emb, int N, int d, const int32_t*
     return MME_OK;
 }
 
-int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms) {
+static int gemm_bench_impl(mme_ctx* c, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms, uint64_t* stamps_host) {
     if (!c || !avg_ms) return MME_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0 || iters < 1 || epilogue < 0 || epilogue > 4)
         return fail(c, MME_E_ARG, "mme_gemm_bench: bad shape / epilogue");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t a_bytes = (size_t)M * K * 2, w_bytes = (size_t)N * K * 2, o_bytes = (size_t)(M + 256) * N * 4;
-    void *A = nullptr, *W = nullptr, *O = nullptr, *B = nullptr, *P = nullptr;
+    void *A = nullptr, *W = nullptr, *O = nullptr, *B = nullptr, *P = nullptr, *ST = nullptr;
+    constexpr size_t kStampBytes = 256 * 2 * 16 * sizeof(uint64_t);
     std::vector<uint16_t> h(((a_bytes > w_bytes ? a_bytes : w_bytes) / 2));
     uint64_t x = 0x9E3779B97F4A7C15ull;
     auto fill = [&](size_t n) {  // uniform [-1,1) bf16 (guide: bench on random data, never zeros)
@@ -772,11 +773,30 @@ int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, i
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         *avg_ms = ms / iters;
+        if (stamps_host) {
+            if (hipMalloc(&ST, kStampBytes) != hipSuccess) { rc = fail(c, MME_E_NOMEM, "mme_gemm_stamps: hipMalloc"); break; }
+            (void)hipMemset(ST, 0, kStampBytes);
+            (void)launch_gemm256r_stamped(g, (unsigned long long*)ST, s);  // warm
+            (void)hipMemset(ST, 0, kStampBytes);
+            hipError_t es = launch_gemm256r_stamped(g, (unsigned long long*)ST, s);
+            if (es != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_gemm_stamps: launch failed"); break; }
+            (void)hipMemcpy(stamps_host, ST, kStampBytes, hipMemcpyDeviceToHost);
+        }
     } while (0);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    for (void* p : {A, W, O, B, P}) if (p) (void)hipFree(p);
+    for (void* p : {A, W, O, B, P, ST}) if (p) (void)hipFree(p);
     return rc;
+}
+
+int mme_gemm_bench(mme_ctx* c, int M, int N, int K, int epilogue, int variant, int iters, double* avg_ms) {
+    return gemm_bench_impl(c, M, N, K, epilogue, variant, iters, avg_ms, nullptr);
+}
+
+int mme_gemm_stamps(mme_ctx* c, int M, int N, int K, uint64_t* stamps_host) {
+    if (!stamps_host) return MME_E_ARG;
+    double ms = 0;
+    return gemm_bench_impl(c, M, N, K, EPI_BIAS, 3, 1, &ms, stamps_host);
 }
 
 int mme_profile_enable(mme_ctx* c, int on) {

@@ -27,8 +27,13 @@ constexpr int LDS_BYTES = 3 * ASLOT + 2 * BSLOT;
 
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tiles_m, int tiles_n, int gn, int dbg) {
+// STAMP: diagnostic build -- waves 0 and 4 accumulate s_memtime intervals between the eight barriers of
+// a K-tile, the time inside the counted wait and the time between two tiles' K loops (split into group
+// sync + prologue issue, epilogue body, rest); 16 words per wave go to `stamps` (layout: mme.h,
+// mme_gemm_stamps).  No stamp executes in the product kernel.
+template <int EPI, bool STAMP = false>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tiles_m, int tiles_n, int gn, int dbg,
+                                                             unsigned long long* stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,9 +77,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         return c;
     };
     // one half tile = 128 rows: pieces 2*wave and 2*wave+1; `rem` clamps the row, `half` = 0/128
+    // (buffer form of LDS-DMA: wave-uniform base in a resource descriptor + one 32-bit lane offset,
+    // half the address traffic of the 64-bit global form)
     auto stage = [&](const char* gbase, int rem, int half, int region) {
-        glds16(gbase + (min(pr0 + half, rem) * ldb + pc0), dst0 + region);
-        glds16(gbase + (min(pr1 + half, rem) * ldb + pc1), dst1 + region);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(dst0 + region), 16, min(pr0 + half, rem) * ldb + pc0, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (LDS_AS void*)(dst1 + region), 16, min(pr1 + half, rem) * ldb + pc1, 0, 0, 0);
     };
     // K-tile 0 completely, then B_lo and A of K-tile 1 (14 DMA pieces per wave)
     auto issue_prologue = [&](const TileCtx& c) {
@@ -92,6 +100,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         }
     };
 
+    unsigned long long st_iv[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_wait = 0, st_epi = 0, st_prev = 0, st_nk = 0, st_pro = 0, st_body = 0;
+    const bool st_on = STAMP && (wave == 0 || wave == 4);
+#define STAMP_IV(i)                                          \
+    if (st_on) {                                             \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        st_iv[i] += now - st_prev;                           \
+        st_prev = now;                                       \
+    }
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     TileCtx cx = make_ctx(tile);
@@ -147,6 +163,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
 
         // a_cur / a_nx2: LDS offsets of the A ring slots of K-tiles t and t+2; b_cur / b_nxt: B ring
         int a_cur = 0, a_nx2 = 2 * ASLOT, b_cur = 0, b_nxt = BSLOT;
+        if (st_on) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (st_prev) st_epi += now - st_prev;
+            st_prev = now;
+            st_nk += nk;
+        }
         for (int t = 0; t < nk; ++t) {
             const bool has1 = t + 1 < nk && (dbg & 3) != 1, has2 = t + 2 < nk && (dbg & 3) != 1;
             const char* w1 = Wg + (size_t)(t + 1) * (TK * 2);
@@ -157,30 +179,40 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             READ_A(a_cur, 0)
             if (has1) stage(w1, nrem, 128, B_RING + b_nxt + HALF);
             S_BARRIER();
+            STAMP_IV(0)
             MFMA_QUAD(0, 0)
             S_BARRIER();
+            STAMP_IV(1)
             /* q1 */
             READ_B(b_cur, 2)
             if (has2) stage(a2, mrem, 0, a_nx2);
             S_BARRIER();
+            STAMP_IV(2)
             MFMA_QUAD(0, 2)
             S_BARRIER();
+            STAMP_IV(3)
             /* q2 */
             READ_A(a_cur, 4)
             if (has2) stage(a2, mrem, 128, a_nx2 + HALF);
             S_BARRIER();
+            STAMP_IV(4)
             MFMA_QUAD(4, 2)
             S_BARRIER();
+            STAMP_IV(5)
             /* q3 */
+            const unsigned long long st_w0 = st_on ? __builtin_amdgcn_s_memtime() : 0;
             if (has2) {
                 stage(w1 + TK * 2, nrem, 0, B_RING + b_cur);
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (st_on) st_wait += __builtin_amdgcn_s_memtime() - st_w0;
             S_BARRIER();
+            STAMP_IV(6)
             MFMA_QUAD(4, 0)
             S_BARRIER();
+            STAMP_IV(7)
             a_cur = a_cur == 2 * ASLOT ? 0 : a_cur + ASLOT;
             a_nx2 = a_nx2 == 2 * ASLOT ? 0 : a_nx2 + ASLOT;
             b_cur ^= BSLOT;
@@ -195,6 +227,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         if (has_next) {
             cx = make_ctx(next_tile);
             issue_prologue(cx);
+        }
+        unsigned long long st_t1 = 0;
+        if (st_on) {
+            st_t1 = __builtin_amdgcn_s_memtime();
+            st_pro += st_t1 - st_prev;
         }
         bool interior = false;
 
@@ -249,12 +286,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
                 }
             }
         }
+        if (st_on) st_body += __builtin_amdgcn_s_memtime() - st_t1;
         if (!has_next) break;
         if (!interior) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unknown store count: drain
         stores_pending = interior && EPI != EPI_PATCH;
         if (interior && EPI == EPI_PATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tile = next_tile;
     }
+    if (st_on && lane == 0 && stamps) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = st_iv[i];
+        o[8] = st_wait;
+        o[9] = st_epi;
+        o[10] = st_nk;
+        o[11] = st_pro;
+        o[12] = st_body;
+    }
+#undef STAMP_IV
 #undef READ_A
 #undef READ_B
 #undef MFMA_QUAD
@@ -286,6 +335,21 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
 }
 
 }  // namespace
+
+// diagnostic launch of the stamped build (bias epilogue only): stamps = uint64[256 * 2 * 16], zeroed by the caller
+hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps, hipStream_t s) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % TK) != 0) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_256r<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
+    const int ntiles = tiles_m * tiles_n;
+    int gn = (int)((2400 * 1024) / ((size_t)TN * g.K * 2));
+    gn = gn < 3 ? 3 : gn;
+    gn = gn > tiles_n ? tiles_n : gn;
+    hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI_BIAS, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), LDS_BYTES, s, g, tiles_m, tiles_n, gn,
+                       0, stamps);
+    return hipGetLastError();
+}
 
 hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;

@@ -33,6 +33,8 @@ struct GemmArgs {
 };
 
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0);
+// diagnostic: stamped build of the 3-deep-ring 256x256 kernel (bias epilogue), stamps uint64[256 * 2 * 16]
+hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps, hipStream_t s);
 
 // LayerNorm over rows of 768 bf16 (f32 statistics), bf16 out.
 hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s);
