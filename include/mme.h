@@ -123,6 +123,21 @@ int mme_crop_boxes(mme_ctx* ctx, const uint8_t* page_dev, int H, int W, const in
 int mme_preprocess(mme_ctx* ctx, const uint8_t* pix_dev, const int64_t* offs_host, const int32_t* hw_host,
                    int n, uint16_t* patches_dev, void* stream);
 
+/* Mllama-faithful multi-tile preprocessing: what `processor(images=[image])`
+ * (embedder.py:117-121) computes with the checkpoint's geometry -- transformers
+ * image_processing_pil_mllama.py:483-541: choose the tile canvas among all grids of <= max_tiles
+ * tiles (:299-355), aspect-preserving Pillow-BILINEAR fit into it (:246-295, :431-481), zero pad to
+ * the canvas, x/255, (x-mean)/std (the values of mme_set_normalisation), split into tiles row-major
+ * (:39-49), zero-pad the tile axis (:84-133).  Bit-exact f32.
+ *   pix_dev / offs_host / hw_host   as mme_preprocess
+ *   tile, max_tiles                 560 and 4 for mmE5-mllama; tile % 8 == 0
+ *   out_dev            float[n, max_tiles, 3, tile, tile]  (`pixel_values`)
+ *   aspect_ids_host    int32[n] or NULL: `aspect_ratio_ids` (1-based index into the supported grids, :136-164)
+ *   num_tiles_host     int32[n] or NULL: tiles used; `aspect_ratio_mask` = 1 for the first num_tiles slots (:52-81)
+ * Synchronises the stream once (crop tables are staged from host temporaries). */
+int mme_preprocess_tiles(mme_ctx* ctx, const uint8_t* pix_dev, const int64_t* offs_host, const int32_t* hw_host, int n, int tile,
+                         int max_tiles, float* out_dev, int32_t* aspect_ids_host, int32_t* num_tiles_host, void* stream);
+
 /* ---- K2-K8: ViT forward + pool + L2 normalise -------------------------------------------
  * Replaces `model(**inputs, output_hidden_states=True)` + `last_pooling`
  * (embedder.py:124-129, :17-34).  pool_token: 0 = [CLS] (default), 196 = last token

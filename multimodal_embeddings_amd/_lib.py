@@ -57,6 +57,8 @@ EXPORTS = {
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_cluster_pages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_preprocess_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     "mme_crop_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -219,6 +221,20 @@ class Engine:
         patches = t.empty((n * 196, 768), dtype=t.bfloat16, device=pix.device)
         self._check(self.lib.mme_preprocess(self.h, pix.data_ptr(), offs.ctypes.data, hw.ctypes.data, n, patches.data_ptr(), self._stream()), "mme_preprocess")
         return patches
+
+    def preprocess_tiles(self, pix, offs, hw, tile=560, max_tiles=4):
+        """Mllama multi-tile preprocessing of packed crops -> (pixel_values f32 CUDA [n, max_tiles, 3, tile, tile],
+        aspect_ratio_ids int64[n], aspect_ratio_mask int64[n, max_tiles], num_tiles list[int])."""
+        t = self.torch
+        offs, hw = self._crop_tables(offs, hw)
+        n = len(offs)
+        out = t.empty((n, max_tiles, 3, tile, tile), dtype=t.float32, device=pix.device)
+        ids = np.zeros(n, dtype=np.int32)
+        nt = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.mme_preprocess_tiles(self.h, pix.data_ptr(), offs.ctypes.data, hw.ctypes.data, n, int(tile), int(max_tiles),
+                                                  out.data_ptr(), ids.ctypes.data, nt.ctypes.data, self._stream()), "mme_preprocess_tiles")
+        mask = (np.arange(max_tiles)[None, :] < nt[:, None]).astype(np.int64)
+        return out, ids.astype(np.int64), mask, nt.tolist()
 
     def vit_forward(self, patches, pool_token: int = 0, want_f32: bool = True, want_bf16: bool = True):
         t = self.torch

@@ -668,6 +668,135 @@ int mme_cluster_pages(mme_ctx* c, const double* S, int P, int n_clusters, int mo
     return MME_OK;
 }
 
+// ---- Mllama tile canvas (transformers image_processing_pil_mllama.py:216-355), f64 like numpy ----
+static void optimal_tile_grid(int h, int w, int max_tiles, int tile, int* th, int* tw) {
+    // supported grids (a, b), a outer / b inner (:216-243), treated as (tiles_h, tiles_w) (:329-332)
+    int ga[64], gb[64], ng = 0;
+    double sc[64];
+    for (int a = 1; a <= max_tiles; ++a)
+        for (int b = 1; b <= max_tiles; ++b)
+            if (a * b <= max_tiles && ng < 64) {
+                const double sh = (double)(a * tile) / (double)h, sw = (double)(b * tile) / (double)w;
+                ga[ng] = a;
+                gb[ng] = b;
+                sc[ng++] = sw > sh ? sh : sw;  // np.where(scale_w > scale_h, scale_h, scale_w)
+            }
+    bool any_up = false;
+    double sel = 0.0;
+    for (int i = 0; i < ng; ++i)
+        if (sc[i] >= 1.0 && (!any_up || sc[i] < sel)) {  // smallest upscaling factor (:337-339)
+            sel = sc[i];
+            any_up = true;
+        }
+    if (!any_up) {
+        bool first = true;
+        for (int i = 0; i < ng; ++i)
+            if (first || sc[i] > sel) {  // largest downscaling factor (:340-343)
+                sel = sc[i];
+                first = false;
+            }
+    }
+    long best_area = -1;
+    for (int i = 0; i < ng; ++i)
+        if (sc[i] == sel) {  // ties: smallest canvas area, first in list order (:346-353)
+            const long area = (long)(ga[i] * tile) * (long)(gb[i] * tile);
+            if (best_area < 0 || area < best_area) {
+                best_area = area;
+                *th = ga[i];
+                *tw = gb[i];
+            }
+        }
+}
+
+static void fit_to_tile_canvas(int h, int w, int canvas_h, int canvas_w, int tile, int* nh, int* nw) {
+    const int target_w = w < tile ? tile : (w > canvas_w ? canvas_w : w);
+    const int target_h = h < tile ? tile : (h > canvas_h ? canvas_h : h);
+    const double scale_h = (double)target_h / (double)h, scale_w = (double)target_w / (double)w;
+    if (scale_w < scale_h) {
+        *nw = target_w;
+        int v = (int)std::floor((double)h * scale_w);
+        if (v == 0) v = 1;
+        *nh = v < target_h ? v : target_h;
+    } else {
+        *nh = target_h;
+        int v = (int)std::floor((double)w * scale_h);
+        if (v == 0) v = 1;
+        *nw = v < target_w ? v : target_w;
+    }
+}
+
+int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const int32_t* hw, int n, int tile, int max_tiles,
+                         float* out, int32_t* aspect_ids_host, int32_t* num_tiles_host, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (n < 0 || tile < 8 || tile > 1024 || (tile % 8) != 0 || max_tiles < 1 || max_tiles > 16)
+        return fail(c, MME_E_ARG, "mme_preprocess_tiles: need n >= 0, tile in 8..1024 (multiple of 8), max_tiles in 1..16");
+    if (n == 0) return MME_OK;
+    if (!pix || !offs || !hw || !out) return fail(c, MME_E_ARG, "mme_preprocess_tiles: null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    c->h_crops.resize(n);
+    c->h_work.clear();
+    std::vector<int32_t> grid((size_t)n * 2);
+    size_t tmp_bytes = 0;
+    int table_ints = 16, band_bytes = 16, taps_cap = 224;
+    constexpr int kBand = 32 * 1024;
+    for (int i = 0; i < n; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h <= 0 || w <= 0 || h > 8000 || w > 8000) return fail(c, MME_E_ARG, "crop %d has size %dx%d (h x w); supported 1..8000", i, h, w);
+        int th = 1, tw = 1;
+        optimal_tile_grid(h, w, max_tiles, tile, &th, &tw);
+        grid[2 * i] = th;
+        grid[2 * i + 1] = tw;
+        CropDesc& d = c->h_crops[i];
+        d.src_off = offs[i];
+        d.h = h;
+        d.w = w;
+        fit_to_tile_canvas(h, w, th * tile, tw * tile, tile, &d.new_h, &d.new_w);
+        d.tmp_off = 0;
+        if (aspect_ids_host) {  // 1 + index of (th, tw) in the supported list (image_processing_pil_mllama.py:136-164)
+            int idx = 0, found = 0;
+            for (int a = 1; a <= max_tiles && !found; ++a)
+                for (int b = 1; b <= max_tiles; ++b) {
+                    if (a * b > max_tiles) continue;
+                    ++idx;
+                    if (a == th && b == tw) { found = idx; break; }
+                }
+            aspect_ids_host[i] = found;
+        }
+        if (num_tiles_host) num_tiles_host[i] = th * tw;
+        if (d.new_w != w) {
+            d.tmp_off = (int64_t)tmp_bytes;
+            tmp_bytes += ((size_t)h * d.new_w * 3 + 15) & ~(size_t)15;
+            const int row_bytes = w * 3;
+            int rows = kBand / row_bytes;
+            rows = rows < 1 ? 1 : (rows > 64 ? 64 : rows);
+            for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
+            const int kstride = 2 * ((w + d.new_w - 1) / d.new_w) + 1;
+            if (d.new_w * kstride > table_ints) table_ints = d.new_w * kstride;
+            const int bb = (rows < h ? rows : h) * row_bytes;
+            if (bb > band_bytes) band_bytes = bb;
+            if (d.new_w > taps_cap) taps_cap = d.new_w;
+        }
+    }
+    int r;
+    const size_t desc_bytes = ((size_t)n * sizeof(CropDesc) + 15) & ~(size_t)15;
+    if ((r = ensure(c, c->crops, desc_bytes + grid.size() * sizeof(int32_t)))) return r;
+    if ((r = ensure(c, c->tmp, tmp_bytes + 16))) return r;
+    if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->crops.p, c->h_crops.data(), (size_t)n * sizeof(CropDesc), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync((char*)c->crops.p + desc_bytes, grid.data(), grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (!c->h_work.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));  // `grid` is a local: its staging copy must be done before it goes away
+    Timed t(c, s, KC_PRE);
+    hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
+                                   table_ints, band_bytes, s, taps_cap);
+    if (e != hipSuccess) return fail(c, MME_E_HIP, "mme_preprocess_tiles: horizontal pass (%s); a %d-wide canvas row of a very wide crop exceeds the LDS budget", hipGetErrorString(e), taps_cap);
+    HIP_TRY(c, launch_resize_v_tiles(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const int32_t*)((char*)c->crops.p + desc_bytes),
+                                     n, c->lut, out, tile, max_tiles, s));
+    return MME_OK;
+}
+
 int mme_crop_boxes(mme_ctx* c, const uint8_t* page, int H, int W, const int32_t* boxes, int n, uint8_t* pix, const int64_t* offs,
                    void* stream) {
     if (!c) return MME_E_ARG;

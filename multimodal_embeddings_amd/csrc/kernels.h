@@ -60,7 +60,10 @@ struct HWork {  // one block of the horizontal pass: a band of source rows of on
     int32_t crop, row0, nrows;
 };
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
-                           int band_bytes, hipStream_t s);
+                           int band_bytes, hipStream_t s, int taps_cap = 224);
+// multi-tile Mllama output: grid_of int32[n,2] (tiles_h, tiles_w); out f32 [n, max_tiles, 3, T, T]
+hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, const int32_t* grid_of, int n,
+                                 const float* lut, float* out, int T, int max_tiles, hipStream_t s);
 // K0: boxes int32[n,4] (x0,y0,x1,y1), offs int64[n] byte offsets into pix; zero fill outside the page
 hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* boxes, const int64_t* offs, const HWork* work, int nwork,
                              uint8_t* pix, hipStream_t s);

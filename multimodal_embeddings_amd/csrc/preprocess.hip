@@ -72,18 +72,18 @@ __device__ __forceinline__ uint8_t clip8(int v) {
 // (all loads in flight at once), then every (row, x, channel) output of the band is computed
 // from LDS in parallel.  Band height is chosen on the host so that a band is <= H_BAND bytes.
 __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
-                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work, int table_ints) {
+                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work, int table_ints, int taps_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HWork wk = work[blockIdx.x];
     const CropDesc c = crops[wk.crop];
     const int tid = threadIdx.x;
     const int row_bytes = c.w * 3;
-    // LDS carve: [224] Taps | coefficient table (per-launch size) | band
+    // LDS carve: [taps_cap] Taps (>= widest output row of the batch) | coefficient table (per-launch size) | band
     Taps* taps = (Taps*)smem;
-    int* kk = (int*)(smem + VIT_IMG * sizeof(Taps));
-    uint8_t* band = (uint8_t*)(smem + VIT_IMG * sizeof(Taps) + (size_t)table_ints * sizeof(int));
+    int* kk = (int*)(smem + (size_t)taps_cap * sizeof(Taps));
+    uint8_t* band = (uint8_t*)(smem + (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int));
     const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;  // >= 2*ceil(max(scale,1))+1
-    if (tid < c.new_w) taps[tid] = compute_taps(c.w, c.new_w, tid, kk + tid * kstride);
+    for (int x = tid; x < c.new_w; x += 256) taps[x] = compute_taps(c.w, c.new_w, x, kk + x * kstride);
     const uint8_t* src = pix + c.src_off + (int64_t)wk.row0 * row_bytes;
     const int nbytes = wk.nrows * row_bytes;
     const uintptr_t a0 = (uintptr_t)src & ~(uintptr_t)15;
@@ -197,6 +197,62 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
     }
 }
 
+// Mllama multi-tile output: vertical pass + zero pad to the tile canvas + normalise +
+// split into tiles, f32 channel-planar [n, max_tiles, 3, T, T] as transformers'
+// image_processing_pil_mllama.py:505-517 produces it (pad BEFORE normalise, tiles row-major over the
+// canvas, unused tile slots all zero).  One workgroup = 8 rows of one tile slot.
+constexpr int TILE_ROWS = 8;
+__global__ __launch_bounds__(256) void resize_v_tiles(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
+                                                      const CropDesc* __restrict__ crops, const int2* __restrict__ grid_of,
+                                                      const float* __restrict__ lut, float* __restrict__ out, int T, int max_tiles) {
+    __shared__ Taps taps[TILE_ROWS];
+    __shared__ int kk[TILE_ROWS * MAX_TAPS];
+    __shared__ float slut[3 * 256];
+    const int blocks_per_tile = T / TILE_ROWS;
+    const int rb = blockIdx.x % blocks_per_tile;
+    const int slot = (blockIdx.x / blocks_per_tile) % max_tiles;
+    const int crop = blockIdx.x / (blocks_per_tile * max_tiles);
+    const CropDesc c = crops[crop];
+    const int th = grid_of[crop].x, tw = grid_of[crop].y;
+    const int tid = threadIdx.x;
+    float* o = out + (((int64_t)crop * max_tiles + slot) * 3) * T * T + (int64_t)rb * TILE_ROWS * T;
+    if (slot >= th * tw) {  // image_processing_pil_mllama.py:117-131: the tile axis is zero padded
+        for (int e = tid; e < 3 * TILE_ROWS * T; e += 256) {
+            const int ch = e / (TILE_ROWS * T), rem = e - ch * (TILE_ROWS * T);
+            o[(int64_t)ch * T * T + rem] = 0.f;
+        }
+        return;
+    }
+    for (int i = tid; i < 768; i += 256) slut[i] = lut[i];
+    const int ty = slot / tw, tx = slot - ty * tw;
+    const int y0 = ty * T + rb * TILE_ROWS, x0 = tx * T;
+    const bool hpass = c.new_w != c.w, vpass = c.new_h != c.h;
+    const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
+    const int64_t srb = (int64_t)c.new_w * 3;
+    if (vpass && tid < TILE_ROWS && y0 + tid < c.new_h) taps[tid] = compute_taps(c.h, c.new_h, y0 + tid, kk + tid * MAX_TAPS);
+    __syncthreads();
+    for (int e = tid; e < 3 * TILE_ROWS * T; e += 256) {
+        const int ch = e / (TILE_ROWS * T), rem = e - ch * (TILE_ROWS * T);
+        const int r = rem / T, x = rem - r * T;
+        const int yy = y0 + r, xx = x0 + x;
+        int v = 0;
+        if (yy < c.new_h && xx < c.new_w) {
+            const uint8_t* p = src + (int64_t)xx * 3 + ch;
+            if (!vpass) {
+                v = p[yy * srb];
+            } else {
+                const Taps t = taps[r];
+                const int* k = kk + r * MAX_TAPS;
+                int ss0 = 1 << (PRECISION_BITS - 1);
+                p += t.xmin * srb;
+                for (int y = 0; y < t.n; ++y) ss0 += (int)p[y * srb] * k[y];
+                v = clip8(ss0);
+            }
+        }
+        o[(int64_t)ch * T * T + rem] = slut[ch * 256 + v];
+    }
+}
+
 // K0: cut every bounding box of ONE decoded page into the packed crop buffer K1 reads.
 // Restates DocLayoutDetector.get_region_image (doclayout_detector.py:178-189): the box corners
 // are already int()-truncated by the caller; `image.crop` keeps the box size and fills what
@@ -229,11 +285,21 @@ hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* b
     return hipGetLastError();
 }
 
+hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, const int32_t* grid_of, int n,
+                                 const float* lut, float* out, int T, int max_tiles, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (T % TILE_ROWS != 0 || max_tiles < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(resize_v_tiles, dim3((unsigned)((int64_t)n * max_tiles * (T / TILE_ROWS))), dim3(256), 0, s, pix, tmp, crops,
+                       (const int2*)grid_of, lut, out, T, max_tiles);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
-                           int band_bytes, hipStream_t s) {
+                           int band_bytes, hipStream_t s, int taps_cap) {
     if (nwork <= 0) return hipSuccess;
     // Taps table + coefficient table (largest of the batch) + one band (+ alignment slack)
-    const size_t smem = VIT_IMG * sizeof(Taps) + (size_t)table_ints * sizeof(int) + (size_t)band_bytes + 48;
+    if (taps_cap < VIT_IMG) taps_cap = VIT_IMG;
+    const size_t smem = (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int) + (size_t)band_bytes + 48;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     static size_t attr_set = 0;
     if (smem > attr_set) {
@@ -241,7 +307,7 @@ hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* cro
         if (e != hipSuccess) return e;
         attr_set = smem;
     }
-    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints);
+    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints, taps_cap);
     return hipGetLastError();
 }
 

@@ -132,6 +132,19 @@ class RegionEmbedder:
         hw = np.tile(np.array([[crops.shape[1], crops.shape[2]]], dtype=np.int32), (n, 1))
         return self.engine.embed(crops.reshape(-1), offs, hw, self.pool_token)
 
+    def process_images(self, images, tile=560, max_tiles=4):
+        """What `self.processors[i](images=[image], return_tensors="pt")` hands the reference's model
+        (embedder.py:117-121), for a batch of single-image samples, computed on the GPU (K1 multi-tile):
+        {"pixel_values": f32 CUDA [B, 1, max_tiles, 3, tile, tile], "aspect_ratio_ids": int64 [B, 1],
+         "aspect_ratio_mask": int64 [B, 1, max_tiles], "num_tiles": [[n], ...]} -- bit-exact with transformers'
+        MllamaImageProcessorPil at the checkpoint geometry (tile 560, <= 4 tiles) when the engine's mean/std are
+        the checkpoint's (the CLIP values by default)."""
+        arrays = [_load_rgb(item) for item in images]
+        pix, offs, hw = self.pack(arrays)
+        pv, ids, mask, nt = self.engine.preprocess_tiles(pix, offs, hw, tile, max_tiles)
+        return {"pixel_values": pv[:, None], "aspect_ratio_ids": ids[:, None], "aspect_ratio_mask": mask[:, None, :],
+                "num_tiles": [[int(v)] for v in nt]}
+
     # -- reference surface ------------------------------------------------------------------------
     def get_image_embeddings(self, image_paths, is_query=False, batch_size=config.BATCH_SIZE):
         """embedder.py:141-226: order-preserving list of float lists with None holes."""

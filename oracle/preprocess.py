@@ -185,3 +185,62 @@ def patchify(pixel_values: np.ndarray, patch: int = PATCH) -> np.ndarray:
 
 def preprocess_to_patches(img: np.ndarray, mean=CLIP_MEAN, std=CLIP_STD) -> np.ndarray:
     return patchify(preprocess_crop(img, mean, std))
+
+
+# ---- Mllama multi-tile preprocessing ------------------------------------------
+# Restates transformers models/mllama/image_processing_pil_mllama.py as the reference's
+# `processor(images=[image])` runs it with the checkpoint's geometry (tile 560, up to 4 tiles).
+
+
+def supported_aspect_ratios(max_tiles: int):
+    """:216-243 -- every (a, b) with a*b <= max_tiles, a outer, b inner."""
+    return [(a, b) for a in range(1, max_tiles + 1) for b in range(1, max_tiles + 1) if a * b <= max_tiles]
+
+
+def optimal_tiled_canvas(h: int, w: int, max_tiles: int, tile: int) -> tuple[int, int]:
+    """:299-355 -- canvas (height, width) in pixels: the smallest upscaling if any canvas fits the image
+    whole, else the largest downscaling; ties -> smallest area, then first in list order."""
+    arr = supported_aspect_ratios(max_tiles)
+    best = None
+    scales = [min((a * tile) / h, (b * tile) / w) if True else 0 for a, b in arr]
+    # np.where(scale_w > scale_h, scale_h, scale_w) == min on finite values
+    up = [s for s in scales if s >= 1]
+    sel = min(up) if up else max(s for s in scales if s < 1)
+    for (a, b), s in zip(arr, scales):
+        if s == sel:
+            area = (a * tile) * (b * tile)
+            if best is None or area < best[0]:
+                best = (area, a * tile, b * tile)
+    return best[1], best[2]
+
+
+def fit_to_canvas_general(h: int, w: int, canvas_h: int, canvas_w: int, tile: int) -> tuple[int, int]:
+    """:246-295 -- aspect-preserving size inside the canvas, never below one tile on the binding axis."""
+    target_w = min(max(w, tile), canvas_w)
+    target_h = min(max(h, tile), canvas_h)
+    scale_h = target_h / h
+    scale_w = target_w / w
+    if scale_w < scale_h:
+        return min(math.floor(h * scale_w) or 1, target_h), target_w
+    return target_h, min(math.floor(w * scale_h) or 1, target_w)
+
+
+def preprocess_tiles(img: np.ndarray, tile: int = 560, max_tiles: int = 4, mean=CLIP_MEAN, std=CLIP_STD):
+    """u8[h,w,3] -> (pixel_values f32[max_tiles,3,tile,tile], aspect_ratio_id, num_tiles, (tiles_h, tiles_w)).
+
+    :483-541: resize into the optimal canvas (:431-481), zero-pad to the canvas (:392-429), rescale,
+    normalise, split into tiles row-major (:39-49), pad the tile axis with zeros (:84-133);
+    aspect_ratio_id = 1 + index of (tiles_h, tiles_w) in the supported list (:136-164)."""
+    h, w = img.shape[:2]
+    ch, cw = optimal_tiled_canvas(h, w, max_tiles, tile)
+    th, tw = ch // tile, cw // tile
+    new_h, new_w = fit_to_canvas_general(h, w, ch, cw, tile)
+    small = pil_bilinear_resize_u8(img, new_h, new_w)
+    canvas = np.zeros((ch, cw, 3), dtype=np.uint8)
+    canvas[:new_h, :new_w] = small
+    lut = normalise_lut(mean, std)
+    full = np.stack([lut[c][canvas[:, :, c]] for c in range(3)])  # [3, ch, cw]
+    tiles = full.reshape(3, th, tile, tw, tile).transpose(1, 3, 0, 2, 4).reshape(th * tw, 3, tile, tile)
+    out = np.zeros((max_tiles, 3, tile, tile), dtype=np.float32)
+    out[: th * tw] = tiles
+    return out, supported_aspect_ratios(max_tiles).index((th, tw)) + 1, th * tw, (th, tw)

@@ -341,6 +341,37 @@ def golden_regions():
     print("region rows golden:", count, "regions;", [c.shape for c in crops])
 
 
+TILE_CASE_SIZES = [(50, 40), (300, 1500), (1500, 300), (600, 600), (1200, 1100), (561, 1130), (2000, 500), (500, 2000), (560, 560),
+                   (7, 5), (559, 561), (1121, 560), (2240, 560), (560, 2240), (3000, 3000), (70, 1200), (1681, 560), (5114, 63),
+                   (20, 3862), (1119, 1121), (1000, 500), (450, 900)]
+
+
+def golden_tiles():
+    """transformers MllamaImageProcessorPil with the checkpoint's geometry (tile 560, <= 4 tiles, CLIP mean/std)
+    on the committed crops and on seeded arrays covering all eight tile arrangements -> tile_cases.json
+    (aspect-ratio ids, tile counts, sha256 + probes of the f32 pixel_values)."""
+    from PIL import Image
+    from transformers.models.mllama.image_processing_pil_mllama import MllamaImageProcessorPil
+
+    from oracle.preprocess import CLIP_MEAN, CLIP_STD
+
+    proc = MllamaImageProcessorPil(size={"height": 560, "width": 560}, max_image_tiles=4, image_mean=list(CLIP_MEAN), image_std=list(CLIP_STD))
+    man = json.load(open(os.path.join(HERE, "crops_manifest.json")))
+    cases = []
+    images = [("file:" + c["file"], np.array(Image.open(os.path.join(HERE, "crops", c["file"])).convert("RGB"))) for c in man["crops"]]
+    for k, (h, w) in enumerate(TILE_CASE_SIZES):
+        images.append((f"seed:{1000 + k}:{h}x{w}", np.random.default_rng(1000 + k).integers(0, 256, (h, w, 3), dtype=np.uint8)))
+    probe = np.random.default_rng(5).integers(0, 4 * 3 * 560 * 560, 24)
+    for name, img in images:
+        out = proc(images=[img], return_tensors="np")
+        pv = np.ascontiguousarray(out["pixel_values"][0, 0])
+        cases.append({"source": name, "hw": list(img.shape[:2]), "aspect_ratio_id": int(out["aspect_ratio_ids"][0, 0]),
+                      "aspect_ratio_mask": out["aspect_ratio_mask"][0, 0].tolist(), "num_tiles": int(out["num_tiles"][0][0]),
+                      "sha256": hashlib.sha256(pv.tobytes()).hexdigest(), "probe": [float(v) for v in pv.reshape(-1)[probe]]})
+    json.dump({"tile": 560, "max_tiles": 4, "probe_index": probe.tolist(), "cases": cases}, open(os.path.join(HERE, "tile_cases.json"), "w"))
+    print("tile golden:", len(cases), "crops; arrangements", sorted({c["aspect_ratio_id"] for c in cases}))
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix="golden_")
     os.chdir(scratch)
@@ -349,6 +380,7 @@ def main():
     if "--only-next" in sys.argv:  # the SURVEY 8(f) rows only (leaves the other fixtures untouched)
         golden_neighbours()
         golden_regions()
+        golden_tiles()
         shutil.rmtree(scratch, ignore_errors=True)
         return
     import torch
@@ -481,6 +513,7 @@ def main():
     print("pagesim cases ok")
     golden_neighbours()
     golden_regions()
+    golden_tiles()
 
     # ---- 5. last_pooling -------------------------------------------------------------
     g = torch.Generator().manual_seed(3)

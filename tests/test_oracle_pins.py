@@ -245,3 +245,30 @@ def test_region_rows_and_crops_match_reference_region_processor(golden_dir):
     for box, shape, sha in zip(kept, g["crop_shapes"], g["crop_sha256"]):
         crop = oreg.crop_region(page, box)
         assert list(crop.shape) == shape and hashlib.sha256(crop.tobytes()).hexdigest() == sha
+
+
+def test_tile_preprocessing_matches_transformers_mllama_processor(golden_dir):
+    """oracle.preprocess_tiles == transformers' MllamaImageProcessorPil at the checkpoint geometry (tile 560,
+    <= 4 tiles): canvas choice, aspect-ratio id / mask, tile count, and every f32 pixel value (sha256) on the
+    committed crops and on seeded arrays that reach all eight tile arrangements."""
+    from PIL import Image
+
+    g = json.load(open(os.path.join(golden_dir, "tile_cases.json")))
+    probe = np.array(g["probe_index"])
+    seen = set()
+    for c in g["cases"]:
+        kind, rest = c["source"].split(":", 1)
+        if kind == "file":
+            img = np.array(Image.open(os.path.join(golden_dir, "crops", rest)).convert("RGB"))
+        else:
+            seed, hw = rest.split(":")
+            h, w = map(int, hw.split("x"))
+            img = np.random.default_rng(int(seed)).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert list(img.shape[:2]) == c["hw"]
+        pv, aid, nt, (th, tw) = opre.preprocess_tiles(img, g["tile"], g["max_tiles"])
+        assert aid == c["aspect_ratio_id"] and nt == c["num_tiles"] == th * tw
+        assert [1] * nt + [0] * (g["max_tiles"] - nt) == c["aspect_ratio_mask"]
+        assert pv.reshape(-1)[probe].tolist() == c["probe"]
+        assert hashlib.sha256(np.ascontiguousarray(pv).tobytes()).hexdigest() == c["sha256"], c["source"]
+        seen.add(aid)
+    assert seen == set(range(1, 9))
