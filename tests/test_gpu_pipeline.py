@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops  # noqa: E402
+from multimodal_embeddings_amd.weights import make_vit_weights, round_to_bf16, synthetic_crops  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -214,3 +214,40 @@ def test_weighted_clustering_run_writes_reference_artefacts(embedder, golden_dir
     assert res["labels"] == want["labels"]
     empty = RegionCollection()
     assert run_weighted_clustering(empty, ["/pages/" + n for n in names], str(tmp_path / "none"), engine=embedder.engine) is None
+
+
+def test_c3_variable_size_crops_at_full_size(embedder, golden_dir):
+    """C3: 4096 crops with the size distribution of the reference's 1862 bundled region crops (20..5114 px high,
+    63..3862 px wide; pixels seeded because the crops themselves cannot travel): patches of a sample are bit-exact
+    with the oracle, embeddings of that sample within 1e-3 cosine, every row unit length, run-to-run identical."""
+    from oracle import preprocess as opre
+    from oracle import vit as ovit
+
+    n = 4096
+    sizes = np.load(os.path.join(golden_dir, "bundled_crop_sizes_hw.npy"))
+    hw = sizes[np.arange(n) % len(sizes)].astype(np.int32)
+    nbytes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+    offs = np.zeros(n, dtype=np.int64)
+    offs[1:] = np.cumsum((nbytes[:-1] + 15) // 16 * 16)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    pix = torch.randint(0, 256, (int(offs[-1] + nbytes[-1]) + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    eng = embedder.engine
+    patches = eng.preprocess(pix, offs, hw)
+    a32, _ = eng.embed(pix, offs, hw, want_bf16=False)
+    b32, _ = eng.embed(pix, offs, hw, want_bf16=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a32, b32) and torch.isfinite(a32).all()
+    assert torch.allclose(a32.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
+    tall, wide = int(np.argmax(hw[:, 0])), int(np.argmax(hw[:, 1]))
+    sample = sorted({0, 1, 777, 2048, 4095, tall, wide, int(np.argmin(hw[:, 0])), int(np.argmin(hw[:, 1]))})
+    host = pix.cpu().numpy()
+    want_patches = []
+    for k in sample:
+        h, w = hw[k]
+        crop = host[offs[k] : offs[k] + nbytes[k]].reshape(h, w, 3)
+        want = opre.preprocess_to_patches(crop)
+        got = patches[k * 196 : (k + 1) * 196].float().cpu().numpy()
+        assert np.array_equal(got, round_to_bf16(want)), (k, h, w)  # K1 emits the oracle's f32 value rounded once to bf16
+        want_patches.append(want)
+    want_emb = ovit.vit_embed(np.stack(want_patches), make_vit_weights(seed=1))
+    assert np.max(1.0 - np.sum(a32[sample].cpu().numpy() * want_emb, axis=1)) <= 1e-3
