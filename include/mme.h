@@ -184,6 +184,14 @@ int mme_page_similarity(mme_ctx* ctx, const uint16_t* emb_dev, int64_t N, int d,
                         int max_query, int top_k, double max_dist, int metric, int normalise, double* S_dev,
                         void* stream);
 
+/* Multi-GPU form: compute only the page pairs whose rank in the row-major upper triangle
+ * (i < j) lies in [pair_lo, pair_hi), un-normalised, every other entry of S_dev = 0.  Ranks split
+ * 0..P(P-1)/2 evenly, add their S (disjoint entries: the sum is exact) and normalise once. */
+int mme_page_similarity_pairs(mme_ctx* ctx, const uint16_t* emb_dev, int64_t N, int d, const double* area_pct_dev,
+                              const uint8_t* valid_dev, const int32_t* page_offs_host, int P, const uint8_t* skip_dev,
+                              int max_query, int top_k, double max_dist, int metric, int64_t pair_lo, int64_t pair_hi,
+                              double* S_dev, void* stream);
+
 /* ---- K11: page clustering -------------------------------------------------------------------
  * Replaces cluster_images' arithmetic (weighted_region_clustering.py:476-543): average
  * linkage + silhouette-chosen k.  S_dev double[P,P] page similarities with unit diagonal

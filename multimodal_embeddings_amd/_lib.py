@@ -56,6 +56,8 @@ EXPORTS = {
     "mme_cosine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "mme_page_similarity_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_int, C.c_double, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     "mme_cluster_pages": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_preprocess_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
@@ -276,12 +278,20 @@ class Engine:
         self._check(self.lib.mme_cosine(self.h, a.data_ptr(), m, b.data_ptr(), n, d, out.data_ptr(), out.stride(0), self._stream()), "mme_cosine")
         return out
 
-    def page_similarity(self, emb, area_pct, valid, page_offs, skip=None, *, max_query=10, top_k=10, max_dist=0.9, metric=0, normalise=True):
+    def page_similarity(self, emb, area_pct, valid, page_offs, skip=None, *, max_query=10, top_k=10, max_dist=0.9, metric=0, normalise=True,
+                        pair_range=None):
+        """pair_range=(lo, hi): only those upper-triangle pair ranks, raw and zero elsewhere (one rank's shard)."""
         t = self.torch
         N, d = emb.shape
         page_offs = np.ascontiguousarray(page_offs, dtype=np.int32)
         P = len(page_offs) - 1
         S = t.empty((P, P), dtype=t.float64, device=emb.device)
+        if pair_range is not None:
+            self._check(self.lib.mme_page_similarity_pairs(self.h, emb.data_ptr(), N, d, area_pct.data_ptr(), valid.data_ptr(), page_offs.ctypes.data,
+                                                           P, skip.data_ptr() if skip is not None else None, int(max_query), int(top_k),
+                                                           float(max_dist), int(metric), int(pair_range[0]), int(pair_range[1]), S.data_ptr(),
+                                                           self._stream()), "mme_page_similarity_pairs")
+            return S
         self._check(self.lib.mme_page_similarity(self.h, emb.data_ptr(), N, d, area_pct.data_ptr(), valid.data_ptr(), page_offs.ctypes.data, P,
                                                  skip.data_ptr() if skip is not None else None, int(max_query), int(top_k), float(max_dist),
                                                  int(metric), int(bool(normalise)), S.data_ptr(), self._stream()), "mme_page_similarity")

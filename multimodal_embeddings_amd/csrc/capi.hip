@@ -611,9 +611,9 @@ int mme_cosine(mme_ctx* c, const uint16_t* a, int m, const uint16_t* b, int n, i
     return MME_OK;
 }
 
-int mme_page_similarity(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const double* area_pct, const uint8_t* valid,
-                        const int32_t* page_offs_host, int P, const uint8_t* skip, int max_query, int top_k, double max_dist,
-                        int metric, int normalise, double* S, void* stream) {
+static int page_similarity_impl(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const double* area_pct, const uint8_t* valid,
+                                const int32_t* page_offs_host, int P, const uint8_t* skip, int max_query, int top_k, double max_dist,
+                                int metric, int normalise, int64_t pair_lo, int64_t pair_hi, double* S, void* stream) {
     if (!c) return MME_E_ARG;
     if (P < 0 || N < 0 || d <= 0 || (d % 64) != 0) return fail(c, MME_E_ARG, "mme_page_similarity: bad sizes (P=%d N=%lld d=%d)", P, (long long)N, d);
     if (P == 0) return MME_OK;
@@ -645,10 +645,27 @@ int mme_page_similarity(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const
     a.emb = emb; a.N = N; a.d = d; a.area_pct = area_pct; a.valid = valid;
     a.page_offs = (const int32_t*)(ws + o_offs); a.P = P; a.skip = skip;
     a.max_query = max_query; a.top_k = top_k; a.max_dist = max_dist; a.metric = metric; a.normalise = normalise;
+    a.pair_lo = pair_lo; a.pair_hi = pair_hi;
     a.S = S; a.qsim = (float*)(ws + o_qsim); a.qrow = (const int32_t*)(ws + o_qrow); a.qpage = (const int32_t*)(ws + o_nval);
     a.qstart = nullptr; a.nq = (int)slots; a.qemb = ws + o_qemb; a.maxbuf = (double*)(ws + o_max);
     HIP_TRY(c, launch_page_similarity(a, s));
     return MME_OK;
+}
+
+int mme_page_similarity(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const double* area_pct, const uint8_t* valid,
+                        const int32_t* page_offs_host, int P, const uint8_t* skip, int max_query, int top_k, double max_dist,
+                        int metric, int normalise, double* S, void* stream) {
+    return page_similarity_impl(c, emb, N, d, area_pct, valid, page_offs_host, P, skip, max_query, top_k, max_dist, metric, normalise, 0, -1,
+                                S, stream);
+}
+
+int mme_page_similarity_pairs(mme_ctx* c, const uint16_t* emb, int64_t N, int d, const double* area_pct, const uint8_t* valid,
+                              const int32_t* page_offs_host, int P, const uint8_t* skip, int max_query, int top_k, double max_dist,
+                              int metric, int64_t pair_lo, int64_t pair_hi, double* S, void* stream) {
+    if (c && (pair_lo < 0 || pair_hi < pair_lo || pair_hi > (int64_t)P * (P - 1) / 2))
+        return fail(c, MME_E_ARG, "mme_page_similarity_pairs: pair range [%lld, %lld) outside 0..P(P-1)/2", (long long)pair_lo, (long long)pair_hi);
+    return page_similarity_impl(c, emb, N, d, area_pct, valid, page_offs_host, P, skip, max_query, top_k, max_dist, metric, 0, pair_lo, pair_hi,
+                                S, stream);
 }
 
 int mme_cluster_pages(mme_ctx* c, const double* S, int P, int n_clusters, int mode, int32_t* labels, int32_t* k_out, double* scores,

@@ -82,6 +82,7 @@ struct PageSimArgs {
     int max_query, top_k;
     double max_dist;
     int metric, normalise;
+    int64_t pair_lo, pair_hi; // upper-triangle pair ranks [lo, hi) computed by this call (multi-GPU shards); hi < 0 = all
     double* S;              // [P,P]
     // workspace
     float* qsim;            // [nq, N] f32

@@ -75,9 +75,8 @@ __global__ __launch_bounds__(256) void page_pairs(PageSimArgs a, const int32_t* 
     __shared__ double terms_all[4][MAX_TERMS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* terms = terms_all[wv];
-    const int64_t pair = (int64_t)blockIdx.x * 4 + wv;
-    const int64_t npairs = (int64_t)a.P * (a.P - 1) / 2;
-    if (pair >= npairs) return;
+    const int64_t pair = a.pair_lo + (int64_t)blockIdx.x * 4 + wv;
+    if (pair >= a.pair_hi) return;
     // unrank pair -> (i, j), i < j, row-major over the upper triangle
     int i = 0;
     {
@@ -202,11 +201,16 @@ hipError_t launch_page_similarity(const PageSimArgs& a, hipStream_t s) {
     g.ldf = a.N;
     hipError_t e = launch_gemm(EPI_F32, g, s);
     if (e != hipSuccess) return e;
-    // diagonal starts at 0 (np.zeros), pairs fill the rest
-    hipLaunchKernelGGL(normalise_S, dim3((unsigned)(((int64_t)a.P * a.P + 255) / 256)), dim3(256), 0, s, a.S, a.P, a.maxbuf, 1);
+    // S starts as np.zeros (wrc:160); this call fills the pairs of its rank range [lo, hi) (all of them
+    // unless a multi-GPU caller shards the upper triangle) and leaves the rest 0, so shards add up exactly
     const int64_t npairs = (int64_t)a.P * (a.P - 1) / 2;
-    if (npairs > 0)
-        hipLaunchKernelGGL(page_pairs, dim3((unsigned)((npairs + 3) / 4)), dim3(256), 0, s, a, qrow, nvalid);
+    PageSimArgs b = a;
+    if (b.pair_hi < 0 || b.pair_hi > npairs) b.pair_hi = npairs;
+    if (b.pair_lo < 0) b.pair_lo = 0;
+    e = hipMemsetAsync(a.S, 0, (size_t)a.P * a.P * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    if (b.pair_hi > b.pair_lo)
+        hipLaunchKernelGGL(page_pairs, dim3((unsigned)((b.pair_hi - b.pair_lo + 3) / 4)), dim3(256), 0, s, b, qrow, nvalid);
     if (a.normalise) {
         hipLaunchKernelGGL(offdiag_max, dim3(1), dim3(1024), 0, s, a.S, a.P, a.maxbuf);
         hipLaunchKernelGGL(normalise_S, dim3((unsigned)(((int64_t)a.P * a.P + 255) / 256)), dim3(256), 0, s, a.S, a.P, a.maxbuf, 0);

@@ -105,3 +105,44 @@ def all_reduce_max_float(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_reduce_sum(t):
+    """In-place sum over ranks (no-op without an initialised process group); returns t."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def normalise_page_matrix(S):
+    """wrc:246-252 on a torch f64 [P, P] tensor: off-diagonal / max off-diagonal (if > 0), diagonal = 1."""
+    import torch
+
+    P = S.shape[0]
+    eye = torch.eye(P, dtype=torch.bool, device=S.device)
+    off = S.masked_fill(eye, float("-inf"))
+    mx = off.max() if P > 1 else torch.tensor(0.0, dtype=S.dtype, device=S.device)
+    out = torch.where(mx > 0, S / mx, S) if P > 1 else S.clone()
+    return out.masked_fill(eye, 1.0)
+
+
+def page_similarity_sharded(emb_all, area_percentage, valid, page_offs, image_names, *, rank=None, world=None, engine=None, **kwargs):
+    """The page matrix with its P(P-1)/2 page pairs split evenly over the ranks: every rank
+    holds all N embeddings (after `all_gather_rows`), computes the pairs of its `shard_range`, the partial
+    matrices -- disjoint entries, zeros elsewhere -- are summed with one all-reduce of P*P f64 (2 MB at
+    P = 512) and normalised identically on every rank.  Bit-identical to the single-GPU result."""
+    import torch.distributed as dist
+
+    from .weighted_region_clustering import page_similarity_from_table
+
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    P = len(page_offs) - 1
+    lo, hi = shard_range(P * (P - 1) // 2, rank, world)
+    S = page_similarity_from_table(emb_all, area_percentage, valid, page_offs, image_names, normalise=False, engine=engine,
+                                   pair_range=(lo, hi), **kwargs)
+    return normalise_page_matrix(all_reduce_sum(S))

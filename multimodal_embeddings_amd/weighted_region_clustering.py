@@ -114,8 +114,11 @@ def build_page_table(all_entries, image_names):
 def page_similarity_from_table(emb, area_percentage, valid, page_offs, image_names, *, metric="cosine",
                                effective_threshold=config.EFFECTIVE_THRESHOLD, skip_same_prefix=True,
                                prefix_length=config.PREFIX_LENGTH, max_query=config.PAGE_QUERY_REGIONS,
-                               top_k=config.PAGE_TOP_K, normalise=True, engine=None):
-    """Device entry: emb may be a bf16 CUDA tensor of unit rows (straight from the embedder)."""
+                               top_k=config.PAGE_TOP_K, normalise=True, engine=None, pair_range=None):
+    """Device entry: emb may be a bf16 CUDA tensor of unit rows (straight from the embedder).
+
+    pair_range=(lo, hi) computes one rank's share of the page pairs (raw, zero elsewhere): see
+    `dist.page_similarity_sharded`."""
     from .cross_compare import to_unit_bf16
 
     engine = engine or default_engine()
@@ -129,7 +132,7 @@ def page_similarity_from_table(emb, area_percentage, valid, page_offs, image_nam
         skip = t.from_numpy(same_prefix_skip(image_names, prefix_length)).to(dev)
     S = engine.page_similarity(e, a, v, page_offs, skip, max_query=max_query, top_k=top_k,
                                max_dist=1.0 - effective_threshold, metric={"cosine": 0, "sqeuclidean": 1}[metric],
-                               normalise=normalise)
+                               normalise=normalise, pair_range=pair_range)
     return S
 
 

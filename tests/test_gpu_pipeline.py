@@ -251,3 +251,44 @@ def test_c3_variable_size_crops_at_full_size(embedder, golden_dir):
         want_patches.append(want)
     want_emb = ovit.vit_embed(np.stack(want_patches), make_vit_weights(seed=1))
     assert np.max(1.0 - np.sum(a32[sample].cpu().numpy() * want_emb, axis=1)) <= 1e-3
+
+
+def test_page_matrix_pair_shards_add_up_to_the_single_gpu_matrix(embedder):
+    """the upper-triangle page pairs split over 8 ranks (computed one after the other on this GPU):
+    partial matrices are disjoint, their sum is the raw matrix bit for bit, and normalising the sum equals the
+    normalised single-GPU matrix."""
+    from multimodal_embeddings_amd import dist as mdist
+    from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+
+    eng = embedder.engine
+    P, per, d = 96, 40, 768
+    N = P * per
+    g = torch.Generator(device="cuda").manual_seed(11)
+    centres = torch.randn(12, d, generator=g, device="cuda") * 1.5
+    e16 = eng.normalise_rows(torch.randn(N, d, generator=g, device="cuda") + centres[torch.randint(0, 12, (N,), generator=g, device="cuda")])
+    rng = np.random.default_rng(3)
+    area = np.exp(rng.uniform(np.log(1e-2), np.log(20.0), N))
+    valid = (rng.random(N) > 0.02).astype(np.uint8)
+    offs = (np.arange(P + 1) * per).astype(np.int32)
+    names = [f"{p:03d} page of the shard test set.png" for p in range(P)]
+    names[5] = names[4][:20] + " dup.png"
+    raw = page_similarity_from_table(e16, area, valid, offs, names, normalise=False, engine=eng)
+    full = page_similarity_from_table(e16, area, valid, offs, names, engine=eng)
+    world = 8
+    total = torch.zeros_like(raw)
+    npairs = P * (P - 1) // 2
+    covered = 0
+    for r in range(world):
+        lo, hi = mdist.shard_range(npairs, r, world)
+        part = page_similarity_from_table(e16, area, valid, offs, names, normalise=False, engine=eng, pair_range=(lo, hi))
+        assert ((part != 0) & (total != 0)).sum() == 0  # disjoint
+        total += part
+        covered += hi - lo
+    assert covered == npairs and torch.equal(total, raw)
+    assert torch.equal(mdist.normalise_page_matrix(total), full)
+    one = mdist.page_similarity_sharded(e16, area, valid, offs, names, engine=eng)  # world size 1: the plain call
+    assert torch.equal(one, full)
+    from multimodal_embeddings_amd._lib import MmeError
+
+    with pytest.raises(MmeError):
+        page_similarity_from_table(e16, area, valid, offs, names, normalise=False, engine=eng, pair_range=(0, npairs + 1))

@@ -208,6 +208,21 @@ block = e[rank * 4:(rank + 1) * 4] @ allv.T
 assert torch.allclose(block, (e @ e.T)[rank * 4:(rank + 1) * 4])
 m = mdist.all_reduce_max_float(float(rank + 1))
 assert m == 2.0
+# page-matrix shards: disjoint partial matrices add up exactly; the normalisation is wrc:246-252
+P = 7
+raw = torch.rand(P, P, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+raw = torch.triu(raw, 1); raw = raw + raw.T
+pairs = [(i, j) for i in range(P) for j in range(i + 1, P)]
+lo, hi = mdist.shard_range(len(pairs), rank, world)
+part = torch.zeros_like(raw)
+for i, j in pairs[lo:hi]:
+    part[i, j] = part[j, i] = raw[i, j]
+tot = mdist.all_reduce_sum(part)
+assert torch.equal(tot, raw), "shard sum"
+S = mdist.normalise_page_matrix(tot)
+off = raw[~torch.eye(P, dtype=torch.bool)]
+assert torch.equal(torch.diagonal(S), torch.ones(P, dtype=torch.float64)) and S[0, 1] == raw[0, 1] / off.max() and S.max() == 1.0
+assert torch.equal(mdist.normalise_page_matrix(torch.zeros(3, 3, dtype=torch.float64)), torch.eye(3, dtype=torch.float64))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
