@@ -4,7 +4,8 @@
 // the staging schedule.  All 160 KiB of LDS are used: a 3-slot ring for the A (activation)
 // half tiles and a 2-slot ring for the B (weight) half tiles.  A comes from HBM / Infinity
 // Cache (an L2 miss costs well over a K-tile of time under load), B is L2 resident, so A is
-// requested TWO K-tiles ahead and B one:
+// requested TWO K-tiles ahead and B one (across output tiles: the stream of K-tiles of a workgroup's
+// consecutive tiles is one stream, see the tile loop):
 //     tile t, q0: B_hi(t+1)   q1: A_lo(t+2)   q2: A_hi(t+2)   q3: B_lo(t+2), s_waitcnt vmcnt(6)
 // vmcnt retires in issue order, so the counted wait in q3 covers B_hi(t+1) and everything older
 // (A(t+1) was issued during tile t-1, B_lo(t+1) in its q3) and leaves the six newest pieces --
@@ -113,12 +114,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
     TileCtx cx = make_ctx(tile);
     issue_prologue(cx);
     issue_prologue_a1(cx);
-    bool stores_pending = false;  // the previous tile's 16 epilogue stores may still be in flight
+    // The operand rings run on ACROSS output tiles: during the last two K-tiles of a tile the look-ahead
+    // slots (B one K-tile ahead, A two) receive the first K-tiles of the workgroup's NEXT tile, so after
+    // the first tile there is no prologue burst and no wait for a first K-tile: it landed, counted by the
+    // ordinary q3 wait, before the epilogue started.
+    // a_cur / a_nx2: LDS offsets of the A ring slots of K-tiles t and t+2; b_cur / b_nxt: B ring
+    int a_cur = 0, a_nx2 = 2 * ASLOT, b_cur = 0, b_nxt = BSLOT;
+    bool first_tile = true;
 
     while (true) {
         const int m0 = cx.m0, n0 = cx.n0, mrem = cx.mrem, nrem = cx.nrem;
         const char* Ag = cx.Ag;
         const char* Wg = cx.Wg;
+        const int next_tile = tile + gridDim.x;
+        const bool has_next = next_tile < ntiles;
+        const TileCtx nx = has_next ? make_ctx(next_tile) : cx;
 
         f32x4 acc[8][4];
 #pragma unroll
@@ -126,16 +136,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // K-tile 0 must have landed; B_lo and A of K-tile 1 (6 pieces) and the previous tile's 16
-        // stores (younger than every prologue piece: vmcnt retires in issue order) may stay in flight.
-        if (stores_pending && nk > 1) {
-            asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-        } else if (stores_pending) {
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        } else if (nk > 1) {
+        // first tile only: K-tile 0 must have landed (B_lo and A of K-tile 1, 6 pieces, may stay in flight);
+        // later tiles found their first K-tiles counted by the previous tile's last q3 wait
+        if (first_tile) {
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            first_tile = false;
         }
         S_BARRIER();
         if (wm == 1) S_BARRIER();  // group 1 runs one barrier behind group 0
@@ -161,8 +166,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             fb[(n_first) + j][ks], fa[i][ks], acc[(m_first) + i][(n_first) + j], 0, 0, 0);     \
     __builtin_amdgcn_s_setprio(0);
 
-        // a_cur / a_nx2: LDS offsets of the A ring slots of K-tiles t and t+2; b_cur / b_nxt: B ring
-        int a_cur = 0, a_nx2 = 2 * ASLOT, b_cur = 0, b_nxt = BSLOT;
         if (st_on) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             if (st_prev) st_epi += now - st_prev;
@@ -170,14 +173,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             st_nk += nk;
         }
         for (int t = 0; t < nk; ++t) {
-            const bool has1 = t + 1 < nk && (dbg & 3) != 1, has2 = t + 2 < nk && (dbg & 3) != 1;
-            const char* w1 = Wg + (size_t)(t + 1) * (TK * 2);
-            const char* a2 = Ag + (size_t)(t + 2) * (TK * 2);
+            // K-tiles t+1 / t+2 of the stream: past the end of this tile they are the next tile's first ones
+            const bool nt1 = t + 1 >= nk, nt2 = t + 2 >= nk;
+            const bool has1 = (!nt1 || has_next) && (dbg & 3) != 1, has2 = (!nt2 || has_next) && (dbg & 3) != 1;
+            const char* w1 = nt1 ? nx.Wg + (size_t)(t + 1 - nk) * (TK * 2) : Wg + (size_t)(t + 1) * (TK * 2);
+            const char* w2 = nt2 ? nx.Wg + (size_t)(t + 2 - nk) * (TK * 2) : Wg + (size_t)(t + 2) * (TK * 2);
+            const char* a2 = nt2 ? nx.Ag + (size_t)(t + 2 - nk) * (TK * 2) : Ag + (size_t)(t + 2) * (TK * 2);
+            const int nrem1 = nt1 ? nx.nrem : nrem, nrem2 = nt2 ? nx.nrem : nrem, mrem2 = nt2 ? nx.mrem : mrem;
             /* q0 */
             READ_B(b_cur, 0)
             __builtin_amdgcn_sched_barrier(0);
             READ_A(a_cur, 0)
-            if (has1) stage(w1, nrem, 128, B_RING + b_nxt + HALF);
+            if (has1) stage(w1, nrem1, 128, B_RING + b_nxt + HALF);
             S_BARRIER();
             STAMP_IV(0)
             MFMA_QUAD(0, 0)
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             STAMP_IV(1)
             /* q1 */
             READ_B(b_cur, 2)
-            if (has2) stage(a2, mrem, 0, a_nx2);
+            if (has2) stage(a2, mrem2, 0, a_nx2);
             S_BARRIER();
             STAMP_IV(2)
             MFMA_QUAD(0, 2)
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             STAMP_IV(3)
             /* q2 */
             READ_A(a_cur, 4)
-            if (has2) stage(a2, mrem, 128, a_nx2 + HALF);
+            if (has2) stage(a2, mrem2, 128, a_nx2 + HALF);
             S_BARRIER();
             STAMP_IV(4)
             MFMA_QUAD(4, 2)
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             /* q3 */
             const unsigned long long st_w0 = st_on ? __builtin_amdgcn_s_memtime() : 0;
             if (has2) {
-                stage(w1 + TK * 2, nrem, 0, B_RING + b_cur);
+                stage(w2, nrem2, 0, B_RING + b_cur);
                 asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -220,29 +227,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         }
         if (wm == 0) S_BARRIER();
 
-        // Every LDS read of this tile is complete: stream the next tile's first K-tile in while
-        // the epilogue below runs (its loads and stores are younger, see the wait above).
-        const int next_tile = tile + gridDim.x;
-        const bool has_next = next_tile < ntiles;
-        if (has_next) {
-            cx = make_ctx(next_tile);
-            issue_prologue(cx);
-        }
         unsigned long long st_t1 = 0;
         if (st_on) {
             st_t1 = __builtin_amdgcn_s_memtime();
             st_pro += st_t1 - st_prev;
         }
-        bool interior = false;
 
         // epilogue: acc[i][j][r] is C[m0 + wm*128 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r].
         // vmcnt counts stores too on CDNA4, so a load inside the store loop would wait for every
         // store issued before it: all loads (bias, residual, positions) are issued first, with
         // row indices clamped instead of branched, and the stores are fire-and-forget.
         const bool fast = EPI != EPI_F32 && n0 + TN <= g.N && m0 + TM <= g.M;
-        if (has_next && !(fast && epi_has_fast_path<EPI>())) issue_prologue_a1(cx);
         if (fast) {
-            interior = true;
             // interior tile: straight-line code, no per-lane predicate (a branch would make the
             // compiler re-insert vmcnt(0) -- i.e. a wait for the stores -- at every join)
             if constexpr (EPI == EPI_PATCH) {
@@ -270,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
                         }
                 }
             } else {
-                if constexpr (epi_has_fast_path<EPI>()) epilogue_wave_128x64<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [&] { if (has_next) issue_prologue_a1(cx); });
+                if constexpr (epi_has_fast_path<EPI>()) epilogue_wave_128x64<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {});
             }
         } else {
 #pragma unroll
@@ -288,9 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         }
         if (st_on) st_body += __builtin_amdgcn_s_memtime() - st_t1;
         if (!has_next) break;
-        if (!interior) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // unknown store count: drain
-        stores_pending = interior && EPI != EPI_PATCH;
-        if (interior && EPI == EPI_PATCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cx = nx;
         tile = next_tile;
     }
     if (st_on && lane == 0 && stamps) {
@@ -338,7 +332,7 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
 
 // diagnostic launch of the stamped build (bias epilogue only): stamps = uint64[256 * 2 * 16], zeroed by the caller
 hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps, hipStream_t s) {
-    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.K % TK) != 0) return hipErrorInvalidValue;
+    if (g.M <= 0 || g.N <= 0 || g.K < 2 * TK || (g.K % TK) != 0) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_256r<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
@@ -351,9 +345,12 @@ hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps
     return hipGetLastError();
 }
 
+hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
+
 hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K <= 0 || (g.K % TK) != 0) return hipErrorInvalidValue;
+    if (g.K < 2 * TK) return launch_gemm256(epilogue, g, s);  // the cross-tile stream looks two K-tiles ahead
     switch (epilogue) {
         case EPI_BIAS: return launch256r<EPI_BIAS>(g, s);
         case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU>(g, s);
