@@ -1,4 +1,4 @@
-// bf16 "TN" GEMM, 256 x 256 x 64 tile, 8 waves, THREE-deep activation ring (variant 5).
+// bf16 "TN" GEMM, 256 x 256 x 64 tile, 8 waves, THREE-deep activation ring (variant 3, the default for large problems).
 //
 // Same wave layout, ping-pong phases, LDS image and epilogues as gemm256.hip; what changes is
 // the staging schedule.  All 160 KiB of LDS are used: a 3-slot ring for the A (activation)

@@ -70,6 +70,22 @@ __device__ __forceinline__ double numpy_pairwise_sum(const double* a, int n) {
     return 0.0 + res;
 }
 
+// wave-wide maximum: quad and row steps as DPP moves, then the four 16-lane rows through SGPRs
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_max(float x) {
+    x = fmaxf(x, dpp_mov<0xB1>(x));   // quad_perm [1,0,3,2]
+    x = fmaxf(x, dpp_mov<0x4E>(x));   // quad_perm [2,3,0,1]
+    x = fmaxf(x, dpp_mov<0x124>(x));  // row_ror:4
+    x = fmaxf(x, dpp_mov<0x128>(x));  // row_ror:8 -> every lane holds its 16-lane row's maximum
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 __global__ __launch_bounds__(256) void page_pairs(PageSimArgs a, const int32_t* __restrict__ qrow_dev,
                                                   const int32_t* __restrict__ nvalid) {
     __shared__ double terms_all[4][MAX_TERMS];
@@ -101,6 +117,37 @@ __global__ __launch_bounds__(256) void page_pairs(PageSimArgs a, const int32_t* 
             const double area_i = a.area_pct[r] / 100.0;
             if (area_i == 0.0) continue;  // wrc:203
             const float* srow = a.qsim + (int64_t)slot * a.N + seg0;
+            if (L <= 256) {
+                // Page segments of up to 256 regions live in four registers per lane (c = lane + 64 t).  d is a
+                // strictly decreasing, exact function of the f32 similarity, so "ascending (d, index)" is
+                // "descending similarity, ascending index": k rounds of wave-max, lowest holder, knock out.
+                float v0 = lane < L ? srow[lane] : -INFINITY, v1 = lane + 64 < L ? srow[lane + 64] : -INFINITY;
+                float v2 = lane + 128 < L ? srow[lane + 128] : -INFINITY, v3 = lane + 192 < L ? srow[lane + 192] : -INFINITY;
+                for (int k = 0; k < n_results; ++k) {
+                    const float M = wave_max(fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+                    if (M == -INFINITY) break;  // segment exhausted
+                    int tsel = 0;
+                    uint64_t bsel = __ballot(v0 == M);
+                    if (!bsel) { bsel = __ballot(v1 == M); tsel = 1; }
+                    if (!bsel) { bsel = __ballot(v2 == M); tsel = 2; }
+                    if (!bsel) { bsel = __ballot(v3 == M); tsel = 3; }
+                    const int lsel = __builtin_ctzll(bsel);
+                    const int best_idx = lsel + 64 * tsel;
+                    if (lane == lsel) {
+                        if (tsel == 0) v0 = -INFINITY;
+                        else if (tsel == 1) v1 = -INFINITY;
+                        else if (tsel == 2) v2 = -INFINITY;
+                        else v3 = -INFINITY;
+                    }
+                    const double best_d = a.metric == 0 ? 1.0 - (double)M : 2.0 - 2.0 * (double)M;
+                    const double area_j = a.area_pct[seg0 + best_idx] / 100.0;
+                    if (best_d <= a.max_dist && area_j > 0.0) {
+                        if (lane == 0 && nterms < MAX_TERMS) terms[nterms] = (1.0 - best_d) * area_i * area_j;
+                        ++nterms;
+                    }
+                }
+                continue;
+            }
             double last_d = -INFINITY;
             int last_idx = -1;
             for (int k = 0; k < n_results; ++k) {

@@ -327,3 +327,31 @@ def test_page_similarity_edge_cases(engine, golden_dir):
     want, _ = ocmp.compute_image_similarity_matrix(None, area, page_of, names, types, skip_same_prefix=False, normalise=False, sim=sims)
     assert np.abs(S - want).max() <= 1e-15
     assert S[2, 3] > 0
+
+
+def test_page_similarity_long_and_short_segments_agree_with_oracle(engine):
+    """Pages of 300 regions take the general selection loop, pages of <= 256 the register-resident one; both must
+    reproduce the oracle's page-pair rule on the kernel's own cosines, duplicates (ties) included."""
+    from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+    from oracle import compare as ocmp
+
+    counts = [300, 7, 256, 257, 64, 1, 130, 300]
+    N, d, P = sum(counts), 64, len(counts)
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(N, d, generator=g, device="cuda") + torch.randn(5, d, generator=g, device="cuda")[torch.randint(0, 5, (N,), generator=g, device="cuda")] * 1.5
+    x[310:330] = x[2]  # exact duplicates inside a short page, of a row of a long one
+    x[700] = x[701]
+    e16 = engine.normalise_rows(x)
+    rng = np.random.default_rng(4)
+    area = np.exp(rng.uniform(np.log(1e-2), np.log(20.0), N))
+    area[rng.random(N) < 0.03] = 0.0
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    names = [f"{p:03d} page of the segment-length test.png" for p in range(P)]
+    S = page_similarity_from_table(e16, area, (area > 0).astype(np.uint8), offs, names, normalise=False, engine=engine).cpu().numpy()
+    sims = engine.cosine(e16, e16).cpu().numpy()
+    page_of = np.repeat(np.arange(P), counts)
+    want, _ = ocmp.compute_image_similarity_matrix(None, area, page_of, names, ["plain_text"] * N, sim=sims)
+    off = S[~np.eye(P, dtype=bool)]
+    S = S / off.max()
+    np.fill_diagonal(S, 1.0)
+    assert np.abs(S - want).max() <= 1e-12
