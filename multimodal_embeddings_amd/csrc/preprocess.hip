@@ -94,15 +94,23 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
     const uint8_t* bb = band + lead;
     const int out_row = c.new_w * 3;
     uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * out_row;
-    for (int e = tid; e < wk.nrows * out_row; e += 256) {
-        const int y = e / out_row, rem = e - y * out_row;
-        const int xx = rem / 3, ch = rem - xx * 3;
+    // one output PIXEL per thread: the three channels share the tap window and every coefficient read
+    for (int e = tid; e < wk.nrows * c.new_w; e += 256) {
+        const int y = e / c.new_w, xx = e - y * c.new_w;
         const Taps t = taps[xx];
         const int* k = kk + xx * kstride;
-        int ss0 = 1 << (PRECISION_BITS - 1);
-        const uint8_t* p = bb + y * row_bytes + t.xmin * 3 + ch;
-        for (int x = 0; x < t.n; ++x) ss0 += (int)p[x * 3] * k[x];
-        dst[e] = clip8(ss0);
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        const uint8_t* p = bb + y * row_bytes + t.xmin * 3;
+        for (int x = 0; x < t.n; ++x) {
+            const int w = k[x];
+            s0 += (int)p[x * 3] * w;
+            s1 += (int)p[x * 3 + 1] * w;
+            s2 += (int)p[x * 3 + 2] * w;
+        }
+        uint8_t* o = dst + (int64_t)e * 3;
+        o[0] = clip8(s0);
+        o[1] = clip8(s1);
+        o[2] = clip8(s2);
     }
 }
 
