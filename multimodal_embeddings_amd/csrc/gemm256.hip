@@ -28,6 +28,7 @@
 //     The next tile's first K-tile is requested BEFORE the epilogue of the current one, so the
 //     epilogue's loads/stores and the prologue latency overlap (K is only 12 K-tiles deep for
 //     three of the four ViT GEMM shapes, so per-tile overhead matters as much as the main loop).
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -281,7 +282,11 @@ hipError_t launch256(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
-    static const int dbg = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;  // timing experiments only
+    static const int dbg = [] {  // timing experiments only: 1 = no K-loop loads, 2 = every tile reads tile 0 (wrong results!)
+        const int v = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;
+        if (v) fprintf(stderr, "libmme: MME_GEMM_DEBUG=%d -- GEMM RESULTS ARE INVALID (timing experiment mode)\n", v);
+        return v;
+    }();
     static const int gn_env = getenv("MME_GEMM_GN") ? atoi(getenv("MME_GEMM_GN")) : 0;
     // column-group width: the group's weight rows (gn x 256 x K bf16) should stay resident in one
     // XCD's 4 MiB L2 next to the streaming A panels and output lines; never split below 3 tiles

@@ -11,6 +11,7 @@
 // (A(t+1) was issued during tile t-1, B_lo(t+1) in its q3) and leaves the six newest pieces --
 // A(t+2) and B_lo(t+2) -- in flight: every A piece has 1.5-1.75 K-tiles to land, B_hi three
 // phases instead of one.
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -316,7 +317,11 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
-    static const int dbg = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;  // timing experiments only
+    static const int dbg = [] {  // timing experiments only: 1 = no K-loop loads, 2 = every tile reads tile 0 (wrong results!)
+        const int v = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;
+        if (v) fprintf(stderr, "libmme: MME_GEMM_DEBUG=%d -- GEMM RESULTS ARE INVALID (timing experiment mode)\n", v);
+        return v;
+    }();
     static const int gn_env = getenv("MME_GEMM_GN") ? atoi(getenv("MME_GEMM_GN")) : 0;
     // column-group width: the group's weight rows (gn x 256 x K bf16) should stay resident in one
     // XCD's 4 MiB L2 next to the streaming A panels and output lines; never split below 3 tiles
