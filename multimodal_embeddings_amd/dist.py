@@ -146,3 +146,22 @@ def page_similarity_sharded(emb_all, area_percentage, valid, page_offs, image_na
     S = page_similarity_from_table(emb_all, area_percentage, valid, page_offs, image_names, normalise=False, engine=engine,
                                    pair_range=(lo, hi), **kwargs)
     return normalise_page_matrix(all_reduce_sum(S))
+
+
+def neighbours_sharded(engine, emb_all, group=None, *, rank=None, world=None, gather=True, **kwargs):
+    """K12 over the ranks: every rank holds all N unit rows (after `all_gather_rows`), ranks its own
+    `shard_range(N)` block of query rows against all N and -- with gather=True -- the [N, top_n] index and
+    similarity tables are assembled on every rank with two all-gathers (ragged shards allowed).
+    Returns (idx int32 [rows, top_n], sim float32 [rows, top_n]); rows = N if gathered, else the shard."""
+    import torch.distributed as dist
+
+    ready = dist.is_available() and dist.is_initialized()
+    world = (dist.get_world_size() if ready else 1) if world is None else world
+    rank = (dist.get_rank() if ready else 0) if rank is None else rank
+    n = emb_all.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    idx, sim = engine.neighbours(emb_all, group, row0=lo, nrows=hi - lo, **kwargs)
+    if not gather or world == 1:
+        return idx, sim
+    counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    return all_gather_rows(idx, counts), all_gather_rows(sim, counts)

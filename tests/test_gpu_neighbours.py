@@ -160,3 +160,16 @@ def test_neighbours_full_size_sampled(engine):
     for k, r in enumerate(sample):
         wi, ws, _ = oc.neighbour_lists(None, group, top_n=10, fetch=30, sim=C[k : k + 1], rows=range(r, r + 1))
         assert idx[r].cpu().numpy().tolist() == wi[0].tolist() and np.array_equal(sim[r].cpu().numpy(), ws[0].astype(np.float32))
+
+
+def test_neighbours_sharded_helper_single_rank_and_emulated_ranks(engine):
+    """dist.neighbours_sharded: world 1 is the plain call; emulated ranks (gather=False) tile the full table."""
+    from multimodal_embeddings_amd import dist as mdist
+
+    e16 = _unit_bf16(engine, 1001, 64, seed=5, clusters=4)
+    group = (np.arange(1001) // 13).astype(np.int32)
+    full_idx, full_sim = engine.neighbours(e16, group, fetch=30, top_n=10)
+    i1, s1 = mdist.neighbours_sharded(engine, e16, group, fetch=30, top_n=10)
+    assert torch.equal(i1, full_idx) and torch.equal(s1, full_sim)
+    parts = [mdist.neighbours_sharded(engine, e16, group, rank=r, world=8, gather=False, fetch=30, top_n=10) for r in range(8)]
+    assert torch.equal(torch.cat([p[0] for p in parts]), full_idx) and torch.equal(torch.cat([p[1] for p in parts]), full_sim)

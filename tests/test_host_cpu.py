@@ -208,6 +208,9 @@ block = e[rank * 4:(rank + 1) * 4] @ allv.T
 assert torch.allclose(block, (e @ e.T)[rank * 4:(rank + 1) * 4])
 m = mdist.all_reduce_max_float(float(rank + 1))
 assert m == 2.0
+# ragged int32 / f32 tables (the neighbour lists of K12) gather like the embeddings
+tab = torch.arange(8 * 3, dtype=torch.int32).reshape(8, 3)
+assert torch.equal(mdist.all_gather_rows(tab[a:b].clone(), counts), tab)
 # page-matrix shards: disjoint partial matrices add up exactly; the normalisation is wrc:246-252
 P = 7
 raw = torch.rand(P, P, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
