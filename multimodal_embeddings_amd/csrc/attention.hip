@@ -37,11 +37,14 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-__global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B) {
+__global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int hsplit) {
     extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x (K | V)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
+    // hsplit workgroups share a crop (small batches: one workgroup per crop would leave most CUs idle and
+    // serialise 12 heads on one); this one walks heads [h_begin, h_end)
+    const int b = blockIdx.x / hsplit, hpw = VIT_H / hsplit;
+    const int h_begin = (blockIdx.x - b * hsplit) * hpw, h_end = h_begin + hpw;
     const char* base = (const char*)qkv + (size_t)b * VIT_T * QKV_LD;
 
     // V rows 200..223 are never written by DMA: zero them once in both buffers (P is 0 there, but
@@ -81,27 +84,27 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
     const char* qp = base + (size_t)min(q, VIT_T - 1) * QKV_LD + hh * 16;
 
     bf16x8 qf[4], qn[4];
-    dma_head(0, 0);
+    dma_head(h_begin, 0);
     if (active) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + h_begin * ROWB + ks * 32);
     }
 
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses VALU arbitration otherwise
-    for (int h = 0; h < VIT_H; ++h) {
-        const int buf = h & 1;
+    for (int h = h_begin; h < h_end; ++h) {
+        const int buf = (h - h_begin) & 1;
         const char* Kl = lds + buf * BUF_BYTES;
         const char* Vl = Kl + KV_BYTES;
         // head h has landed (each wave waits for its own pieces), everybody is done with head h-1
         // (the 4 output stores of head h-1 are this wave's youngest vector-memory operations and may
         // stay in flight: vmcnt retires in order and counts stores)
-        if (h == 0 || !active) {
+        if (h == h_begin || !active) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         }
         S_BARRIER();
-        if (h + 1 < VIT_H) {
+        if (h + 1 < h_end) {
             dma_head(h + 1, buf ^ 1);
             if (active) {
 #pragma unroll
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i & 1][db]), pf, o[db], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (h + 1 < VIT_H) {  // before the stores: the wait for the prefetched Q must not cover them
+            if (h + 1 < h_end) {  // before the stores: the wait for the prefetched Q must not cover them
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
             }
@@ -239,6 +242,12 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(attn_fwd_t197, dim3(B), dim3(512), smem, s, (const bf16_t*)qkv, (bf16_t*)out, B);
+    // enough workgroups for two per CU-slot: split a crop's heads over 1, 2, 3, 4, 6 or 12 workgroups
+    int hsplit = 1;
+    for (int d : {1, 2, 3, 4, 6, 12}) {
+        hsplit = d;
+        if (B * d >= 512) break;
+    }
+    hipLaunchKernelGGL(attn_fwd_t197, dim3(B * hsplit), dim3(512), smem, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit);
     return hipGetLastError();
 }
