@@ -345,8 +345,11 @@ hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps
     int gn = (int)((2400 * 1024) / ((size_t)TN * g.K * 2));
     gn = gn < 3 ? 3 : gn;
     gn = gn > tiles_n ? tiles_n : gn;
-    hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI_BIAS, true>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), LDS_BYTES, s, g, tiles_m, tiles_n, gn,
-                       0, stamps);
+    // MME_GEMM_GRID: run the stamped build on fewer workgroups (does the epilogue's store cost depend on how
+    // many CUs store at the same time?)
+    int grid = ntiles < 256 ? ntiles : 256;
+    if (getenv("MME_GEMM_GRID") && atoi(getenv("MME_GEMM_GRID")) > 0 && atoi(getenv("MME_GEMM_GRID")) < grid) grid = atoi(getenv("MME_GEMM_GRID"));
+    hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI_BIAS, true>), dim3(grid), dim3(512), LDS_BYTES, s, g, tiles_m, tiles_n, gn, 0, stamps);
     return hipGetLastError();
 }
 
