@@ -73,8 +73,14 @@ def cpu_baseline(sample_crops: np.ndarray, weights, budget_s: float = 20.0):
     e = np.stack(embs)
     _ = e @ e.T
     dt = time.perf_counter() - t0
+    # the same port at batch 16 (a fairer best case for the CPU than the reference's one-crop loop)
+    t1 = time.perf_counter()
+    nb = min(16, len(sample_crops))
+    ovit.vit_embed(np.stack([opre.preprocess_to_patches(c) for c in sample_crops[:nb]]), weights, batch=nb)
+    dt16 = time.perf_counter() - t1
     return {
         "value": done / dt,
+        "value_batch16": nb / dt16,
         "unit": "region-crops/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
