@@ -218,12 +218,19 @@ int mme_cluster_pages(mme_ctx* ctx, const double* S_dev, int P, int n_clusters, 
  * [min_sim, max_sim] (:269), keep the first top_n (:352).
  *   fetch, top_n  1..128 (the reference uses fetch = min(3 top_n, 100), top_n = 10)
  *   idx_dev   int32[nrows, top_n] row indices, -1 padded;  sim_dev  float[nrows, top_n] cosine
- * The [rows, N] cosine block is produced chunk-wise by the MFMA GEMM into an internal workspace
- * (<= 2 GiB) and consumed by a one-wave-per-row streaming top-k; S is never materialised.
+ * Small N: the [rows, N] cosine block is produced chunk-wise by the MFMA GEMM into an internal workspace
+ * (<= 2 GiB) and consumed by a one-wave-per-row streaming top-k.  N >= 16384: fused, the block is never written
+ * (mme_set_neighbour_mode).  S is never materialised either way.
  * Multi-GPU: each rank passes its own [row0, row0 + nrows) against the all-gathered emb. */
 int mme_neighbours(mme_ctx* ctx, const uint16_t* emb_dev, int N, int d, const int32_t* group_dev, int row0, int nrows,
                    int fetch, int top_n, int keep_self, float min_sim, float max_sim, int32_t* idx_dev, float* sim_dev,
                    void* stream);
+
+/* K12 execution form: 0 = by size (default), 1 = the [rows, N] cosine block goes through the workspace in chunks,
+ * 2 = fused (N >= 16384): a sampled per-row threshold, then the cosine GEMM appends only the values above it to
+ * per-row candidate lists -- the block is never written; lists that overflow re-run their chunk in form 1 on the
+ * device's own decision.  Results are identical. */
+int mme_set_neighbour_mode(mme_ctx* ctx, int mode);
 
 /* Diagnostic: time one MFMA GEMM shape on random bf16 data (allocates its own operands;
  * synchronous).  epilogue 0 bias, 1 bias+GELU, 2 bias+residual, 3 patch-embed, 4 f32 out;

@@ -64,6 +64,7 @@ EXPORTS = {
     "mme_crop_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_set_neighbour_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mme_gemm_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -314,6 +315,11 @@ class Engine:
                                                scores.data_ptr(), self._stream()), "mme_cluster_pages")
         sc = scores.cpu().numpy()
         return labels.cpu().numpy().tolist(), int(k.item()), [(i, float(sc[i])) for i in range(2, 16) if sc[i] == sc[i]]
+
+    def set_neighbour_mode(self, mode):
+        """0 / "auto", 1 / "block", 2 / "fused" (see mme.h)."""
+        m = {"auto": 0, "block": 1, "fused": 2}.get(mode, mode)
+        self._check(self.lib.mme_set_neighbour_mode(self.h, int(m)), "mme_set_neighbour_mode")
 
     def neighbours(self, emb_bf16, group=None, *, row0=0, nrows=None, fetch=30, top_n=10, keep_self=False,
                    min_sim=-float("inf"), max_sim=float("inf")):

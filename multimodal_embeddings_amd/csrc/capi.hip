@@ -50,6 +50,7 @@ struct mme_ctx {
     int chunk = 4096;
     int gemm_variant = 0;
     bool fuse_ln = true;
+    int neigh_mode = 0;  // K12: 0 by size, 1 cosine block through the workspace, 2 fused candidate lists
     // weights
     std::vector<void*> allocs;
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
@@ -862,18 +863,85 @@ int mme_neighbours(mme_ctx* c, const uint16_t* emb, int N, int d, const int32_t*
     int64_t rc = (ws_mb << 20) / (ldq * 4);
     rc = rc < 256 ? 256 : (rc / 256) * 256;
     if (rc > nrows) rc = nrows;
+    const int nchunks = (int)((nrows + rc - 1) / rc);
+
+    // Fused form (large N): the cosine block is never written.  (1) a strided sample of the rows (every 8th)
+    // gives, per query, a lower bound tau on its fetch-th best similarity; (2) the full GEMM runs with the
+    // EPI_TOPK epilogue, which appends every (value >= tau, column) to the query's candidate list instead of
+    // storing the tile; (3) the same streaming selection runs over the short lists.  A full list (clustered
+    // data beating the 4x margin) raises a device flag that arms an unfused re-run of that chunk -- decided
+    // on the device, so the call stays asynchronous and the result exact either way.
+    constexpr int kStride = 8;
+    const int ns = N / kStride;
+    const int64_t tiles256 = ((int64_t)(rc + 255) / 256) * ((N + 255) / 256);
+    const bool fused = c->neigh_mode != 1 && d >= 128 && ns >= 2048 && ns >= fetch && tiles256 >= 256 && (c->neigh_mode == 2 || N >= 16384);
+    if (c->neigh_mode == 2 && !fused)
+        return fail(c, MME_E_ARG, "mme_neighbours: the fused form needs N >= 16384 rows and >= 256 cosine tiles per chunk (N=%d, rows=%d)", N, nrows);
+    const int64_t ldqs = ((int64_t)ns + 3) & ~(int64_t)3;
+    int64_t cap = 32 * (int64_t)fetch;
+    cap = cap < 256 ? 256 : (cap > 8192 ? 8192 : cap);
+    size_t o_qsim = 0, o_samp = 0, o_qs = 0, o_tidx = 0, o_tsim = 0, o_cnt = 0, o_flag = 0, o_cval = 0, o_cidx = 0, total = (size_t)rc * ldq * 4;
+    if (fused) {
+        auto carve = [&](size_t bytes) { const size_t o = total; total += (bytes + 255) & ~(size_t)255; return o; };
+        o_samp = carve((size_t)ns * d * 2);
+        o_qs = carve((size_t)rc * ldqs * 4);
+        o_tidx = carve((size_t)rc * fetch * 4);
+        o_tsim = carve((size_t)rc * fetch * 4);
+        o_cnt = carve((size_t)rc * 4);
+        o_flag = carve((size_t)nchunks * 4);
+        o_cval = carve((size_t)rc * cap * 4);
+        o_cidx = carve((size_t)rc * cap * 4);
+    }
     int r;
-    if ((r = ensure(c, c->neigh_ws, (size_t)rc * ldq * 4))) return r;
-    float* qsim = (float*)c->neigh_ws.p;
+    if ((r = ensure(c, c->neigh_ws, total))) return r;
+    char* ws = (char*)c->neigh_ws.p;
+    float* qsim = (float*)(ws + o_qsim);
     Timed t(c, s, KC_NEIGH);
+    if (fused) {
+        HIP_TRY(c, hipMemcpy2DAsync(ws + o_samp, (size_t)d * 2, emb, (size_t)kStride * d * 2, (size_t)d * 2, ns, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(ws + o_flag, 0, (size_t)nchunks * 4, s));
+    }
     for (int64_t c0 = 0; c0 < nrows; c0 += rc) {
         const int m = (int)(nrows - c0 < rc ? nrows - c0 : rc);
+        const int q0 = (int)(row0 + c0);
+        int32_t* idx_o = idx + (size_t)c0 * top_n;
+        float* sim_o = sim + (size_t)c0 * top_n;
         GemmArgs g{};
-        g.A = emb + (size_t)(row0 + c0) * d; g.W = emb; g.M = m; g.N = N; g.K = d; g.outf = qsim; g.ldf = ldq;
-        HIP_TRY(c, launch_gemm(EPI_F32, g, s, c->gemm_variant));
-        HIP_TRY(c, launch_topk_rows(qsim, ldq, N, m, (int)(row0 + c0), group, fetch, top_n, keep_self, min_sim, max_sim,
-                                    idx + (size_t)c0 * top_n, sim + (size_t)c0 * top_n, s));
+        g.A = emb + (size_t)q0 * d; g.W = emb; g.M = m; g.N = N; g.K = d; g.outf = qsim; g.ldf = ldq;
+        if (!fused) {
+            HIP_TRY(c, launch_gemm(EPI_F32, g, s, c->gemm_variant));
+            HIP_TRY(c, launch_topk_rows(qsim, ldq, N, m, q0, group, fetch, top_n, keep_self, min_sim, max_sim, idx_o, sim_o, s));
+            continue;
+        }
+        int* flag = (int*)(ws + o_flag) + (int)(c0 / rc);
+        float* tsim = (float*)(ws + o_tsim);
+        // (1) thresholds from the sample: fetch-th best of [m, ns]
+        GemmArgs gs = g;
+        gs.W = ws + o_samp; gs.N = ns; gs.outf = (float*)(ws + o_qs); gs.ldf = ldqs;
+        HIP_TRY(c, launch_gemm(EPI_F32, gs, s, c->gemm_variant));
+        HIP_TRY(c, launch_topk_rows((const float*)(ws + o_qs), ldqs, ns, m, 0, nullptr, fetch, fetch, 1, -INFINITY, INFINITY,
+                                    (int32_t*)(ws + o_tidx), tsim, s));
+        // (2) full GEMM, candidates only
+        HIP_TRY(c, hipMemsetAsync(ws + o_cnt, 0, (size_t)m * 4, s));
+        GemmArgs gf = g;
+        gf.outf = nullptr; gf.thr = tsim + (fetch - 1); gf.thr_stride = fetch; gf.cand_count = (int*)(ws + o_cnt);
+        gf.cand_val = (float*)(ws + o_cval); gf.cand_idx = (int*)(ws + o_cidx); gf.cand_cap = (int)cap; gf.overflow = flag;
+        HIP_TRY(c, launch_gemm(EPI_TOPK, gf, s, 3));
+        // (3) exact selection over the candidate lists
+        HIP_TRY(c, launch_topk_candidates(gf.cand_val, gf.cand_idx, gf.cand_count, (int)cap, m, q0, group, fetch, top_n, keep_self, min_sim,
+                                          max_sim, idx_o, sim_o, s));
+        // fallback, armed on the device by an overflowing list
+        g.run_if = flag;
+        HIP_TRY(c, launch_gemm(EPI_F32, g, s, 3));
+        HIP_TRY(c, launch_topk_rows(qsim, ldq, N, m, q0, group, fetch, top_n, keep_self, min_sim, max_sim, idx_o, sim_o, s, flag));
     }
+    return MME_OK;
+}
+
+int mme_set_neighbour_mode(mme_ctx* c, int mode) {
+    if (!c) return MME_E_ARG;
+    if (mode < 0 || mode > 2) return fail(c, MME_E_ARG, "mme_set_neighbour_mode: 0 (by size), 1 (cosine block through the workspace) or 2 (fused candidate lists)");
+    c->neigh_mode = mode;
     return MME_OK;
 }
 

@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
     }
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
+    if (g.run_if && *g.run_if == 0) return;  // device-side switch of a fallback launch (uniform)
     TileCtx cx = make_ctx(tile);
     issue_prologue(cx);
     issue_prologue_a1(cx);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         // vmcnt counts stores too on CDNA4, so a load inside the store loop would wait for every
         // store issued before it: all loads (bias, residual, positions) are issued first, with
         // row indices clamped instead of branched, and the stores are fire-and-forget.
-        const bool fast = EPI != EPI_F32 && n0 + TN <= g.N && m0 + TM <= g.M;
+        const bool fast = EPI != EPI_F32 && EPI != EPI_TOPK && n0 + TN <= g.N && m0 + TM <= g.M;
         if (fast) {
             // interior tile: straight-line code, no per-lane predicate (a branch would make the
             // compiler re-insert vmcnt(0) -- i.e. a wait for the stores -- at every join)
@@ -268,6 +269,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
                 }
             } else {
                 if constexpr (epi_has_fast_path<EPI>()) epilogue_wave_128x64<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {});
+            }
+        } else if constexpr (EPI == EPI_TOPK) {
+            // candidate filter: the eight row thresholds of this lane are loaded once; a (row, 16-column)
+            // fragment is looked at element by element only if one of its four values reaches the bar
+            float tau[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + wm * 128 + i * 16 + fr;
+                tau[i] = m < g.M ? g.thr[(int64_t)m * g.thr_stride] : INFINITY;
+            }
+            // slots are reserved with ONE returning atomic per (lane, row) -- all eight issued before any
+            // result is needed -- instead of one round trip per hit
+            const int nb = n0 + wn * 64 + fq * 4;
+            int cnt[8], base[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int h = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h += (acc[i][j][r] >= tau[i] && nb + j * 16 + r < g.N) ? 1 : 0;
+                cnt[i] = h;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) base[i] = cnt[i] ? atomicAdd(g.cand_count + (m0 + wm * 128 + i * 16 + fr), cnt[i]) : 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (!cnt[i]) continue;
+                const int64_t row = (int64_t)(m0 + wm * 128 + i * 16 + fr) * g.cand_cap;
+                int k = base[i];
+                if (k + cnt[i] > g.cand_cap) atomicOr(g.overflow, 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (acc[i][j][r] >= tau[i] && nb + j * 16 + r < g.N) {
+                            if (k < g.cand_cap) {
+                                g.cand_val[row + k] = acc[i][j][r];
+                                g.cand_idx[row + k] = nb + j * 16 + r;
+                            }
+                            ++k;
+                        }
             }
         } else {
 #pragma unroll
@@ -367,6 +410,7 @@ hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s) {
         case EPI_F32: return launch256r<EPI_F32>(g, s);
         case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS>(g, s);
         case EPI_LN_BIAS_GELU: return launch256r<EPI_LN_BIAS_GELU>(g, s);
+        case EPI_TOPK: return launch256r<EPI_TOPK>(g, s);
         default: return hipErrorInvalidValue;
     }
 }

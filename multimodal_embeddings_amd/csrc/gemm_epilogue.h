@@ -42,6 +42,21 @@ __device__ __forceinline__ EpiRow epi_row(int m) {
 // v = accumulator values for (m, n..n+3); n < N and n % 4 == 0 guaranteed by the caller.
 template <int EPI>
 __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, const EpiRow& er, int n, f32x4 v) {
+    if (EPI == EPI_TOPK) {
+        const float tau = g.thr[(int64_t)m * g.thr_stride];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + r < g.N && v[r] >= tau) {
+                const int k = atomicAdd(g.cand_count + m, 1);
+                if (k < g.cand_cap) {
+                    g.cand_val[(int64_t)m * g.cand_cap + k] = v[r];
+                    g.cand_idx[(int64_t)m * g.cand_cap + k] = n + r;
+                } else {
+                    atomicOr(g.overflow, 1);
+                }
+            }
+        return;
+    }
     if (EPI == EPI_F32) {
         float* o = g.outf + (int64_t)m * g.ldf + n;
         if (n + 3 < g.N && ((g.ldf & 3) == 0)) {

@@ -14,7 +14,8 @@ enum GemmEpilogue {
     // LayerNorm folded into the GEMM that consumes it (A = the raw residual stream x, W' = W*gamma):
     //   out = bf16(rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n])             (QKV)
     EPI_LN_BIAS = 5,
-    EPI_LN_BIAS_GELU = 6  // same, then erf-GELU                                      (fc1)
+    EPI_LN_BIAS_GELU = 6, // same, then erf-GELU                                      (fc1)
+    EPI_TOPK = 7          // no output matrix: every acc[m,n] >= thr[m] is appended to row m's candidate list (K12)
 };
 
 struct GemmArgs {
@@ -30,6 +31,16 @@ struct GemmArgs {
     int64_t ldf;
     const float* ln_stats;  // [M,2] (mean, rstd) per row, for EPI_LN_*
     const float* colsum;    // [N] sum_k W'[n,k], for EPI_LN_*
+    // EPI_TOPK: per-row threshold thr[m * thr_stride]; candidates (value, column) of row m go to
+    // cand_val / cand_idx [m * cand_cap + k], k = atomic slot from cand_count[m]; a full list raises *overflow
+    const float* thr;
+    int thr_stride;
+    int* cand_count;
+    float* cand_val;
+    int* cand_idx;
+    int cand_cap;
+    int* overflow;
+    const int* run_if;      // optional: the whole launch is a no-op unless *run_if != 0 (device-side fallback switch)
 };
 
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0);
@@ -98,7 +109,12 @@ hipError_t launch_page_similarity(const PageSimArgs& a, hipStream_t s);
 // K12 ranked neighbour lists (neighbours.hip): one wave per row of qsim[nrows, ld] keeps the best `fetch`
 // entries in (similarity desc, index asc) order, then filters self / group / score window into top_n
 hipError_t launch_topk_rows(const float* qsim, int64_t ld, int N, int nrows, int row0, const int32_t* group, int fetch, int top_n,
-                            int keep_self, float min_sim, float max_sim, int32_t* idx_out, float* sim_out, hipStream_t s);
+                            int keep_self, float min_sim, float max_sim, int32_t* idx_out, float* sim_out, hipStream_t s,
+                            const int* run_if = nullptr);
+// the same selection over per-row candidate lists (value, column id) produced by the EPI_TOPK GEMM epilogue
+hipError_t launch_topk_candidates(const float* cand_val, const int32_t* cand_idx, const int32_t* len, int cap, int nrows, int row0,
+                                  const int32_t* group, int fetch, int top_n, int keep_self, float min_sim, float max_sim,
+                                  int32_t* idx_out, float* sim_out, hipStream_t s);
 
 // K11 page clustering (cluster.hip): labels_out int32[P], k_out int32[1], scores_out double[16]
 hipError_t launch_cluster(const double* S, int P, int n_clusters, int mode, char* ws, int32_t* labels_out, int32_t* k_out,

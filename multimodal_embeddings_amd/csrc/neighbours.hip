@@ -31,15 +31,22 @@ __device__ __forceinline__ float lane_of(float x, int l) { return __builtin_bit_
 __device__ __forceinline__ int lane_of(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 
 // HI: the list is longer than 64 entries (positions 64.. live in a second register per lane)
-template <bool HI>
+// MAPPED: the row is a candidate list (fused path): `len[row]` valid entries whose column ids are
+// idx_map[row * ld + position]; ties and the self / group tests use those ids, so the result does not depend
+// on the (atomic, arbitrary) order the candidates were appended in.
+template <bool HI, bool MAPPED>
 __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ qsim, int64_t ld, int N, int nrows, int row0,
                                                  const int32_t* __restrict__ group, int fetch, int top_n, int keep_self,
                                                  float min_sim, float max_sim, int32_t* __restrict__ idx_out,
-                                                 float* __restrict__ sim_out) {
+                                                 float* __restrict__ sim_out, const int32_t* __restrict__ len,
+                                                 const int32_t* __restrict__ idx_map, const int* __restrict__ run_if) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;  // whole wave
+    if (run_if && *run_if == 0) return;
     const float* src = qsim + (int64_t)row * ld;
+    const int32_t* map = MAPPED ? idx_map + (int64_t)row * ld : nullptr;
+    if (MAPPED) N = min(len[row], (int)ld);
 
     float v_lo = -INFINITY, v_hi = -INFINITY;
     int i_lo = INT_MAX, i_hi = INT_MAX;
@@ -79,6 +86,12 @@ __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ qsim,
     // rows start 16-byte aligned (ld % 4 == 0): 4 consecutive values per lane, 1 KiB per wave step,
     // two steps in flight
     const int steps = (N + 255) / 256;
+    auto load_ids = [&](int st) -> int4 {  // column ids of the 4 values of this lane
+        const int j = st * 256 + 4 * lane;
+        if (!MAPPED) return make_int4(j, j + 1, j + 2, j + 3);
+        if (j + 3 < N) return *(const int4*)(map + j);
+        return make_int4(j < N ? map[j] : 0, j + 1 < N ? map[j + 1] : 0, j + 2 < N ? map[j + 2] : 0, 0);
+    };
     auto load = [&](int st) -> float4 {
         const int j = st * 256 + 4 * lane;
         if (j + 3 < N) return *(const float4*)(src + j);
@@ -89,23 +102,27 @@ __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ qsim,
         r.w = -INFINITY;
         return r;
     };
-    float4 cur = load(0);
+    float4 cur = steps > 0 ? load(0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    int4 cid = steps > 0 ? load_ids(0) : make_int4(0, 0, 0, 0);
     for (int st = 0; st < steps; ++st) {
         const float4 nxt = st + 1 < steps ? load(st + 1) : cur;
+        const int4 nid = st + 1 < steps ? load_ids(st + 1) : cid;
         const float e[4] = {cur.x, cur.y, cur.z, cur.w};
+        const int id[4] = {cid.x, cid.y, cid.z, cid.w};
         const int j0 = st * 256 + 4 * lane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            uint64_t m = __ballot(j0 + k < N && better(e[k], j0 + k, thr_v, thr_i));
+            uint64_t m = __ballot(j0 + k < N && better(e[k], id[k], thr_v, thr_i));
             while (m) {
                 const int l = __builtin_ctzll(m);
                 m &= m - 1;
                 const float cv = lane_of(e[k], l);
-                const int ci = st * 256 + 4 * l + k;
+                const int ci = lane_of(id[k], l);
                 if (better(cv, ci, thr_v, thr_i)) insert(cv, ci);  // the bar may have risen meanwhile
             }
         }
         cur = nxt;
+        cid = nid;
     }
 
     // walk the list in order: drop the query, its group, and scores outside the window
@@ -142,14 +159,30 @@ __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ qsim,
 }  // namespace
 
 hipError_t launch_topk_rows(const float* qsim, int64_t ld, int N, int nrows, int row0, const int32_t* group, int fetch, int top_n,
-                            int keep_self, float min_sim, float max_sim, int32_t* idx_out, float* sim_out, hipStream_t s) {
+                            int keep_self, float min_sim, float max_sim, int32_t* idx_out, float* sim_out, hipStream_t s,
+                            const int* run_if) {
     if (nrows <= 0) return hipSuccess;
     if (fetch < 1 || fetch > 128 || top_n < 1 || top_n > 128 || (ld & 3) != 0 || N < 1) return hipErrorInvalidValue;
     if (fetch > 64)
-        hipLaunchKernelGGL(topk_rows<true>, dim3((nrows + 3) / 4), dim3(256), 0, s, qsim, ld, N, nrows, row0, group, fetch, top_n,
-                           keep_self, min_sim, max_sim, idx_out, sim_out);
+        hipLaunchKernelGGL((topk_rows<true, false>), dim3((nrows + 3) / 4), dim3(256), 0, s, qsim, ld, N, nrows, row0, group, fetch, top_n,
+                           keep_self, min_sim, max_sim, idx_out, sim_out, nullptr, nullptr, run_if);
     else
-        hipLaunchKernelGGL(topk_rows<false>, dim3((nrows + 3) / 4), dim3(256), 0, s, qsim, ld, N, nrows, row0, group, fetch, top_n,
-                           keep_self, min_sim, max_sim, idx_out, sim_out);
+        hipLaunchKernelGGL((topk_rows<false, false>), dim3((nrows + 3) / 4), dim3(256), 0, s, qsim, ld, N, nrows, row0, group, fetch, top_n,
+                           keep_self, min_sim, max_sim, idx_out, sim_out, nullptr, nullptr, run_if);
+    return hipGetLastError();
+}
+
+// candidate lists of the fused path: cand_val / cand_idx [nrows, cap], len[nrows] entries appended per row
+hipError_t launch_topk_candidates(const float* cand_val, const int32_t* cand_idx, const int32_t* len, int cap, int nrows, int row0,
+                                  const int32_t* group, int fetch, int top_n, int keep_self, float min_sim, float max_sim,
+                                  int32_t* idx_out, float* sim_out, hipStream_t s) {
+    if (nrows <= 0) return hipSuccess;
+    if (fetch < 1 || fetch > 128 || top_n < 1 || top_n > 128 || (cap & 3) != 0 || cap < 4) return hipErrorInvalidValue;
+    if (fetch > 64)
+        hipLaunchKernelGGL((topk_rows<true, true>), dim3((nrows + 3) / 4), dim3(256), 0, s, cand_val, (int64_t)cap, cap, nrows, row0, group, fetch,
+                           top_n, keep_self, min_sim, max_sim, idx_out, sim_out, len, cand_idx, nullptr);
+    else
+        hipLaunchKernelGGL((topk_rows<false, true>), dim3((nrows + 3) / 4), dim3(256), 0, s, cand_val, (int64_t)cap, cap, nrows, row0, group, fetch,
+                           top_n, keep_self, min_sim, max_sim, idx_out, sim_out, len, cand_idx, nullptr);
     return hipGetLastError();
 }

@@ -173,3 +173,47 @@ def test_neighbours_sharded_helper_single_rank_and_emulated_ranks(engine):
     assert torch.equal(i1, full_idx) and torch.equal(s1, full_sim)
     parts = [mdist.neighbours_sharded(engine, e16, group, rank=r, world=8, gather=False, fetch=30, top_n=10) for r in range(8)]
     assert torch.equal(torch.cat([p[0] for p in parts]), full_idx) and torch.equal(torch.cat([p[1] for p in parts]), full_sim)
+
+
+@pytest.mark.parametrize("kind", ["clustered", "near_duplicates", "wide_fetch"])
+def test_fused_and_block_forms_are_identical(engine, kind):
+    """K12 fused form (sampled threshold -> GEMM epilogue appends candidates -> selection over the lists) against
+    the block form (cosine block through the workspace): same indices, same similarities, bit for bit --
+    including when candidate lists overflow (near-duplicate rows) and the device re-runs the chunk unfused."""
+    n, d = 20000, 128
+    g = torch.Generator(device="cuda").manual_seed(77)
+    if kind == "near_duplicates":
+        centres = torch.randn(3, d, generator=g, device="cuda")
+        x = centres[torch.randint(0, 3, (n,), generator=g, device="cuda")] + 1e-3 * torch.randn(n, d, generator=g, device="cuda")
+        x[500:900] = x[17]  # exact copies as well
+    else:
+        centres = torch.randn(50, d, generator=g, device="cuda") * 1.5
+        x = torch.randn(n, d, generator=g, device="cuda") + centres[torch.randint(0, 50, (n,), generator=g, device="cuda")]
+    e16 = engine.normalise_rows(x)
+    group = torch.from_numpy((np.arange(n) // 37).astype(np.int32)).cuda()
+    kw = dict(fetch=128, top_n=128, keep_self=True) if kind == "wide_fetch" else dict(fetch=30, top_n=10, min_sim=0.1)
+    try:
+        engine.set_neighbour_mode("block")
+        bi, bs = engine.neighbours(e16, None if kind == "wide_fetch" else group, **kw)
+        engine.set_neighbour_mode("fused")
+        fi, fs = engine.neighbours(e16, None if kind == "wide_fetch" else group, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(fi, bi) and torch.equal(fs, bs)
+        # a shard of the rows in the fused form
+        si, ss = engine.neighbours(e16, None if kind == "wide_fetch" else group, row0=4096, nrows=12000, **kw)
+        assert torch.equal(si, bi[4096:16096]) and torch.equal(ss, bs[4096:16096])
+    finally:
+        engine.set_neighbour_mode("auto")
+
+
+def test_fused_form_refuses_problems_it_cannot_take(engine):
+    from multimodal_embeddings_amd._lib import MmeError
+
+    e16 = _unit_bf16(engine, 3000, 64, seed=8)
+    engine.set_neighbour_mode("fused")
+    try:
+        with pytest.raises(MmeError):
+            engine.neighbours(e16, None)
+    finally:
+        engine.set_neighbour_mode("auto")
+    assert engine.neighbours(e16, None)[0].shape == (3000, 10)
