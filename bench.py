@@ -38,7 +38,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 # output written once (bf16), residual read once; weights (85.8 M bf16 per forward pass) added per pass
 BYTES_GEMM_PER_CROP = 12 * 197 * 2 * ((768 + 2304) + 3 * 768 + (768 + 3072) + (3072 + 2 * 768)) + (196 + 197) * 768 * 2
 BYTES_GEMM_WEIGHTS = 2 * (768 * 768 + 12 * (2304 * 768 + 768 * 768 + 2 * 3072 * 768))
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "round1_v9_gemm_traffic.json")  # tools/traffic_json.py, PMC passes of this bench
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "round1_v10_gemm_traffic.json")  # tools/traffic_json.py, PMC passes of this bench
 
 
 def measured_traffic():
@@ -175,7 +175,7 @@ def main():
             "unit": "TFLOP/s",
             "frac": (ach / MFMA_BF16_PEAK_TFLOPS) if ach else None,
             "traffic": measured_traffic() if n == CROPS_PER_GPU else None,
-            "traffic_unit": "bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_v9_gemm_traffic.json)",
+            "traffic_unit": "bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, profiles/round1_v10_gemm_traffic.json)",
             "algorithmic_bytes_per_launch": (BYTES_GEMM_PER_CROP * n + BYTES_GEMM_WEIGHTS * (gemm_launches / steps / 49.0)) / (gemm_launches / steps) if gemm_launches else None,
             "launches_per_step": gemm_launches / steps,
             "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
