@@ -1,4 +1,5 @@
-// bf16 "TN" GEMM, 256 x 256 x 64 tile, 8 waves -- the large-M kernel of the ViT forward.
+// bf16 "TN" GEMM, 256 x 256 x 64 tile, 8 waves, 2-slot operand ring (variant 2; kept for A/B and for K < 128 --
+// the default for large problems is gemm256r.hip, the same kernel with a 3-deep activation ring).
 //
 //   C[M,N] = A[M,K] . W[N,K]^T (+ fused epilogue), both operands K-contiguous.
 //
