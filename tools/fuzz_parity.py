@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Randomised parity sweeps of the GPU kernels against the oracle (run on a GPU box; ~1.5 minutes):
+
+    python tools/fuzz_parity.py
+
+  k1          480 random crop sizes (tiny, extreme aspect, near 224, large): patches and Mllama tiles bit-exact
+  neighbours   60 random (N, D, fetch, top_n, groups, duplicates, score windows): indices and values exact
+  fused        14 problems of 16-42 k rows: fused K12 form == block form (overflow fallback included)
+  pages        25 random page tables (empty pages, > 256 regions, zero areas, foreign types, both metrics): 1e-12
+  cluster      40 random page matrices x 2 modes x (auto, fixed k): labels and k exact, heavy ties included
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from multimodal_embeddings_amd.embedder import RegionEmbedder
+from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+from multimodal_embeddings_amd.weights import round_to_bf16
+from oracle import cluster as oc_cluster
+from oracle import compare as oc
+from oracle import compare as ocmp
+from oracle import preprocess as opre
+
+def fuzz_k1(eng, emb):
+    rng = np.random.default_rng(2024)
+    bad = 0
+    t0 = time.time()
+    for rep in range(12):
+        sizes = []
+        for _ in range(40):
+            kind = rng.integers(0, 5)
+            if kind == 0: h, w = rng.integers(1, 40), rng.integers(1, 40)
+            elif kind == 1: h, w = rng.integers(1, 30), rng.integers(200, 2500)
+            elif kind == 2: h, w = rng.integers(200, 2500), rng.integers(1, 30)
+            elif kind == 3: h, w = rng.integers(180, 270), rng.integers(180, 270)
+            else: h, w = rng.integers(50, 1500), rng.integers(50, 1500)
+            sizes.append((int(h), int(w)))
+        arrays = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in sizes]
+        pix, offs, hw = emb.pack(arrays)
+        patches = emb.engine.preprocess(pix, offs, hw).float().cpu().numpy()
+        pv, ids, mask, nt = emb.engine.preprocess_tiles(pix, offs, hw, 560, 4)
+        pv = pv.cpu().numpy()
+        for k, a in enumerate(arrays):
+            want = round_to_bf16(opre.preprocess_to_patches(a))
+            if not np.array_equal(patches[k * 196:(k + 1) * 196], want):
+                bad += 1; print("PATCH MISMATCH", sizes[k], flush=True)
+            wt, aid, n_t, _ = opre.preprocess_tiles(a, 560, 4)
+            if not (np.array_equal(pv[k], wt) and int(ids[k]) == aid and nt[k] == n_t):
+                bad += 1; print("TILE MISMATCH", sizes[k], flush=True)
+        print("rep", rep, "ok so far, bad =", bad, "t =", round(time.time() - t0, 1), flush=True)
+    return bad
+
+
+def fuzz_neighbours(eng, emb):
+    rng = np.random.default_rng(7)
+    bad = 0
+    for it in range(60):
+        n = int(rng.integers(1, 2500)); d = int(rng.choice([64, 128, 768]))
+        fetch = int(rng.integers(1, 129)); top_n = int(rng.integers(1, 129))
+        g = torch.Generator(device="cuda").manual_seed(it)
+        x = torch.randn(n, d, generator=g, device="cuda")
+        ncl = int(rng.integers(1, 9))
+        x = x + 1.5 * torch.randn(ncl, d, generator=g, device="cuda")[torch.randint(0, ncl, (n,), generator=g, device="cuda")]
+        for _ in range(int(rng.integers(0, 6))):
+            a, b = rng.integers(0, n, 2); x[a] = x[b]
+        e16 = eng.normalise_rows(x)
+        group = rng.integers(0, max(1, n // int(rng.integers(1, 40))) + 1, n).astype(np.int32) if rng.random() < 0.7 else None
+        keep_self = bool(rng.random() < 0.3)
+        lo, hi = (float(rng.uniform(-0.2, 0.3)), float(rng.uniform(0.4, 1.1))) if rng.random() < 0.5 else (-np.inf, np.inf)
+        idx, sim = eng.neighbours(e16, group, fetch=fetch, top_n=top_n, keep_self=keep_self, min_sim=lo, max_sim=hi)
+        C = eng.cosine(e16, e16).cpu().numpy()
+        wi, ws, _ = oc.neighbour_lists(None, group, top_n=top_n, fetch=fetch, sim=C, keep_self=keep_self, min_sim=np.float32(lo), max_sim=np.float32(hi))
+        ok = np.array_equal(idx.cpu().numpy(), wi) and np.array_equal(sim.cpu().numpy(), np.where(wi >= 0, ws, 0).astype(np.float32))
+        if not ok:
+            bad += 1; print("MISMATCH", it, n, d, fetch, top_n, keep_self, lo, hi, flush=True)
+    return bad
+
+
+def fuzz_fused(eng, emb):
+    rng = np.random.default_rng(11)
+    bad = 0
+    for it in range(14):
+        n = int(rng.integers(16384, 42000)); d = int(rng.choice([128, 256, 768]))
+        fetch = int(rng.integers(1, 129)); top_n = int(rng.integers(1, fetch + 1))
+        g = torch.Generator(device="cuda").manual_seed(100 + it)
+        ncl = int(rng.choice([1, 3, 40, 400]))
+        spread = float(rng.choice([1e-3, 0.3, 1.0]))
+        x = spread * torch.randn(n, d, generator=g, device="cuda") + torch.randn(ncl, d, generator=g, device="cuda")[torch.randint(0, ncl, (n,), generator=g, device="cuda")]
+        e16 = eng.normalise_rows(x)
+        group = torch.from_numpy(rng.integers(0, n // 50 + 1, n).astype(np.int32)).cuda() if rng.random() < 0.6 else None
+        row0 = int(rng.integers(0, 2000)); nrows = int(rng.integers(9000, n - row0))
+        kw = dict(row0=row0, nrows=nrows, fetch=fetch, top_n=top_n, keep_self=bool(rng.random() < 0.3))
+        eng.set_neighbour_mode("block"); bi, bs = eng.neighbours(e16, group, **kw)
+        eng.set_neighbour_mode("fused")
+        try:
+            fi, fs = eng.neighbours(e16, group, **kw)
+        except Exception as e:
+            print("fused refused", n, nrows, str(e)[:80]); continue
+        finally:
+            eng.set_neighbour_mode("auto")
+        ok = torch.equal(fi, bi) and torch.equal(fs, bs)
+        print(it, n, d, fetch, top_n, ncl, spread, "ok" if ok else "MISMATCH", flush=True)
+        bad += (not ok)
+    return bad
+
+
+def fuzz_pages(eng, emb):
+    rng = np.random.default_rng(5)
+    bad = 0
+    for it in range(25):
+        P = int(rng.integers(2, 30))
+        counts = [int(rng.choice([0, 1, 3, 9, 10, 11, 40, 130, 256, 257, 300], p=[.05,.05,.1,.1,.1,.1,.2,.15,.05,.05,.05])) for _ in range(P)]
+        N = sum(counts)
+        if N < 2: continue
+        d = int(rng.choice([64, 128]))
+        g = torch.Generator(device="cuda").manual_seed(300 + it)
+        x = torch.randn(N, d, generator=g, device="cuda") + 1.2 * torch.randn(4, d, generator=g, device="cuda")[torch.randint(0, 4, (N,), generator=g, device="cuda")]
+        for _ in range(int(rng.integers(0, 8))):
+            a, b = rng.integers(0, N, 2); x[a] = x[b]
+        e16 = eng.normalise_rows(x)
+        area = np.exp(rng.uniform(np.log(1e-2), np.log(20.0), N)); area[rng.random(N) < 0.05] = 0.0
+        types_ok = rng.random(N) > 0.04
+        valid = ((area > 0) & types_ok).astype(np.uint8)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        names = [f"{p:03d} page of fuzz table number {it:02d}.png" for p in range(P)]
+        if P > 3: names[2] = names[1][:20] + " dup.png"
+        metric = str(rng.choice(["cosine", "sqeuclidean"]))
+        S = page_similarity_from_table(e16, area, valid, offs, names, metric=metric, engine=eng).cpu().numpy()
+        sims = eng.cosine(e16, e16).cpu().numpy()
+        page_of = np.repeat(np.arange(P), counts)
+        types = ["plain_text" if t else "abandon" for t in types_ok]
+        want, _ = ocmp.compute_image_similarity_matrix(None, area, page_of, names, types, sim=sims, metric=metric)
+        err = np.abs(S - want).max()
+        if not err <= 1e-12:
+            bad += 1; print("MISMATCH", it, P, counts, metric, err, flush=True)
+    return bad
+
+
+def fuzz_cluster(eng, emb):
+    rng = np.random.default_rng(3)
+    bad = 0
+    for it in range(40):
+        P = int(rng.integers(2, 120))
+        A = rng.random((P, P)); S = (A + A.T) / 2
+        kind = it % 5
+        if kind == 1:
+            S[rng.random((P, P)) < 0.6] = 0; S = np.minimum(S, S.T)
+        elif kind == 2:
+            gidx = rng.integers(0, 5, P); S = 0.2 * S + 0.7 * (gidx[:, None] == gidx[None, :])
+        elif kind == 3:
+            S = np.round(S * 4) / 4  # heavy ties
+        elif kind == 4:
+            S = np.zeros((P, P)); 
+            for _ in range(P // 2):
+                a, b = rng.integers(0, P, 2)
+                if a != b: S[a, b] = S[b, a] = rng.random()
+        mx = np.max(S - np.diag(np.diag(S)))
+        if mx > 0: S = S / mx
+        np.fill_diagonal(S, 1.0)
+        names = [f"p{i}" for i in range(P)]
+        for mode in ("reference_fallback", "precomputed"):
+            for fixed in (None, int(rng.integers(2, min(P, 12) + 1)) if P >= 2 else None):
+                try:
+                    want = oc_cluster.cluster_images(S.copy(), names, n_clusters=fixed, mode=mode)
+                except Exception as e:
+                    want = None
+                try:
+                    labels, k, scores = eng.cluster_pages(S, n_clusters=fixed, mode=mode)
+                except Exception as e:
+                    labels = None
+                if want is None or labels is None:
+                    if (want is None) != (labels is None):
+                        bad += 1; print("ERR MISMATCH", it, P, mode, fixed, want is None, labels is None, flush=True)
+                    continue
+                if labels != want["labels"] or k != want["n_clusters"]:
+                    bad += 1; print("MISMATCH", it, P, kind, mode, fixed, k, want["n_clusters"], flush=True)
+    return bad
+
+
+def main():
+    emb = RegionEmbedder()
+    eng = emb.engine
+    total = 0
+    for name, fn in [("k1", fuzz_k1), ("neighbours", fuzz_neighbours), ("fused", fuzz_fused), ("pages", fuzz_pages), ("cluster", fuzz_cluster)]:
+        t0 = time.time()
+        bad = fn(eng, emb)
+        print(f"{name}: {bad} mismatches ({time.time() - t0:.1f} s)", flush=True)
+        total += bad
+    print("TOTAL mismatches:", total)
+    sys.exit(1 if total else 0)
+
+
+if __name__ == "__main__":
+    main()
