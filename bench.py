@@ -41,6 +41,27 @@ BYTES_GEMM_WEIGHTS = 2 * (768 * 768 + 12 * (2304 * 768 + 768 * 768 + 2 * 3072 * 
 TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "round1_v10_gemm_traffic.json")  # tools/traffic_json.py, PMC passes of this bench
 
 
+MFMA_UTIL_PROFILE = os.path.join(ROOT, "profiles", "round1_v9_mfma_util.json")  # from the SQ / GRBM PMC passes of this bench
+
+
+def rocprof_mfma_util():
+    """rocprof-reported matrix-pipe utilisation of the forward (busy cycles / available SIMD cycles at the clock the
+    chip actually held), from the committed PMC passes; None when the record is absent."""
+    try:
+        with open(MFMA_UTIL_PROFILE) as fh:
+            return float(json.load(fh)["forward_mfma_util"])
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
+
+
+def baseline_metric_name():
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+            return json.load(fh)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "region-crops/sec embedded + all-pairs cosine, 224\u00d7224, 1/2/4/8 MI355X"
+
+
 def measured_traffic():
     """HBM-side bytes per GEMM launch from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (separate runs of this same command; 2 x FETCH_SIZE + WRITE_SIZE, see profiles/README.md)."""
@@ -167,6 +188,10 @@ def main():
         gemm_ms, gemm_launches = prof["gemm"]
         gemm_ms_step = gemm_ms / steps
         ach = (FLOP_GEMM_PER_CROP * n) / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms > 0 else None
+        cos_ms = prof["cosine"][0] / steps if prof["cosine"][1] else None
+        cos_bytes = float(n) * n * world * 4 + float(n) * world * 768 * 2 + float(n) * 768 * 2  # f32 block written + bf16 rows read
+        cosine_hbm = {"achieved": cos_bytes / (cos_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": cos_bytes / (cos_ms * 1e-3) / 8e12,
+                      "bytes": cos_bytes} if cos_ms else None
         roofline = {
             "kernel": "gemm_bf16_tn (K2/K4/K6/K7 launches of the ViT forward)",
             "bound": "mfma",
@@ -182,7 +207,7 @@ def main():
             "flop_per_launch_avg": FLOP_GEMM_PER_CROP * n / (gemm_launches / steps) if gemm_launches else None,
         }
         out = {
-            "metric": "region-crops/sec embedded + all-pairs cosine, 224x224",
+            "metric": baseline_metric_name(),
             "value": value,
             "unit": "region-crops/s",
             "n_gpus": world,
@@ -201,7 +226,9 @@ def main():
                 "parallelism": f"dp{world} (crop shards, one RCCL all-gather of bf16 embeddings)" if world > 1 else "single GPU",
             },
             "forward_mfma_frac": FLOP_FORWARD_PER_CROP * (n * steps / elapsed) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+            "forward_mfma_util_rocprof": rocprof_mfma_util() if n == CROPS_PER_GPU else None,
             "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
+            "cosine_hbm": cosine_hbm,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
