@@ -242,7 +242,8 @@ int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant,
  * wave processed -- [0..7] the eight barrier-to-barrier intervals of a K-tile, [8] time in the counted wait,
  * [9] everything between two tiles' K loops, [10] K-tiles processed, [11] of [9]: group sync + next tile's
  * prologue issue, [12] of [9]: epilogue body (loads, math, store issue); the rest of [9] is the wait for the
- * next tile's first K-tile. */
+ * next tile's first K-tile; [13] s_memtime cycles and [14] s_memrealtime ticks (100 MHz) of the whole kernel:
+ * [13] / [14] x 100 MHz is the clock the chip held (the call runs ~0.5 s of the product kernel first). */
 int mme_gemm_stamps(mme_ctx* ctx, int M, int N, int K, uint64_t* stamps_host);
 
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------

@@ -235,13 +235,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 
 hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    static bool attr_set = false;
     const int smem = 2 * BUF_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_t197, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197, smem); e != hipSuccess) return e;
     // enough workgroups for two per CU-slot: split a crop's heads over 1, 2, 3, 4, 6 or 12 workgroups
     int hsplit = 1;
     for (int d : {1, 2, 3, 4, 6, 12}) {

@@ -273,13 +273,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256(GemmArgs g, int tiles
 
 template <int EPI>
 hipError_t launch256(const GemmArgs& g, hipStream_t s) {
-    static bool attr_set = false;
     const int smem = 2 * SLOT;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_256<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)gemm_bf16_tn_256<EPI>, smem); e != hipSuccess) return e;
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU

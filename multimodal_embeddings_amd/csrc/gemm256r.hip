@@ -113,6 +113,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     if (g.run_if && *g.run_if == 0) return;  // device-side switch of a fallback launch (uniform)
+    // clock the chip holds under this kernel: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime)
+    const unsigned long long st_c0 = st_on ? __builtin_amdgcn_s_memtime() : 0, st_r0 = st_on ? __builtin_amdgcn_s_memrealtime() : 0;
     TileCtx cx = make_ctx(tile);
     issue_prologue(cx);
     issue_prologue_a1(cx);
@@ -340,6 +342,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         o[10] = st_nk;
         o[11] = st_pro;
         o[12] = st_body;
+        o[13] = __builtin_amdgcn_s_memtime() - st_c0;
+        o[14] = __builtin_amdgcn_s_memrealtime() - st_r0;
     }
 #undef STAMP_IV
 #undef READ_A
@@ -350,13 +354,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
 
 template <int EPI>
 hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
-    static bool attr_set = false;
     const int smem = LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_256r<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)gemm_bf16_tn_256r<EPI>, smem); e != hipSuccess) return e;
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
@@ -381,7 +380,7 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
 // diagnostic launch of the stamped build (bias epilogue only): stamps = uint64[256 * 2 * 16], zeroed by the caller
 hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K < 2 * TK || (g.K % TK) != 0) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_tn_256r<EPI_BIAS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = ensure_dynamic_lds((const void*)gemm_bf16_tn_256r<EPI_BIAS, true>, LDS_BYTES);
     if (e != hipSuccess) return e;
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;

@@ -43,6 +43,10 @@ struct GemmArgs {
     const int* run_if;      // optional: the whole launch is a no-op unless *run_if != 0 (device-side fallback switch)
 };
 
+// raises hipFuncAttributeMaxDynamicSharedMemorySize of `kernel` on the CURRENT device to at least `bytes`
+// (once per (device, kernel), thread-safe: launch_state.hip)
+hipError_t ensure_dynamic_lds(const void* kernel, int bytes);
+
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant = 0);
 // diagnostic: stamped build of the 3-deep-ring 256x256 kernel (bias epilogue), stamps uint64[256 * 2 * 16]
 hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps, hipStream_t s);

@@ -309,12 +309,7 @@ hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* cro
     if (taps_cap < VIT_IMG) taps_cap = VIT_IMG;
     const size_t smem = (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int) + (size_t)band_bytes + 48;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    static size_t attr_set = 0;
-    if (smem > attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)resize_h, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        attr_set = smem;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)resize_h, (int)smem); e != hipSuccess) return e;
     hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints, taps_cap);
     return hipGetLastError();
 }

@@ -64,16 +64,20 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
-def all_gather_rows(local, counts=None):
+def all_gather_rows(local, counts=None, out=None):
     """Gather row blocks `[n_r, D]` from every rank into `[sum n_r, D]` on every rank.
 
-    Equal shards use one `all_gather_into_tensor`; ragged shards are padded to the largest
-    shard (counts = rows per rank, known from shard_range without communication).
+    Equal shards use one `all_gather_into_tensor` (straight into `out` when the caller provides
+    the `[sum n_r, D]` destination, e.g. a slice of a resident table); ragged shards are padded to
+    the largest shard (counts = rows per rank, known from shard_range without communication).
     """
     import torch
     import torch.distributed as dist
 
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        if out is not None:
+            out.copy_(local)
+            return out
         return local
     world = dist.get_world_size()
     n_local, d = local.shape
@@ -82,18 +86,41 @@ def all_gather_rows(local, counts=None):
     counts = [int(c) for c in counts]
     assert counts[dist.get_rank()] == n_local, "counts disagree with the local shard"
     mx = max(counts)
+    ragged = any(c != mx for c in counts)
     # gloo implements neither bf16 nor int16 all_gather: 16-bit payloads travel as bytes
-    payload = local.contiguous().view(torch.uint8) if local.dtype == torch.bfloat16 else local
-    d = payload.shape[1]
+    as_bytes = local.dtype == torch.bfloat16
+    payload = local.contiguous().view(torch.uint8) if as_bytes else local
+    db = payload.shape[1]
     if mx != n_local:
-        pad = torch.zeros((mx - n_local, d), dtype=payload.dtype, device=payload.device)
+        pad = torch.zeros((mx - n_local, db), dtype=payload.dtype, device=payload.device)
         payload = torch.cat([payload, pad], dim=0)
     payload = payload.contiguous()
-    out = torch.empty((world * mx, d), dtype=payload.dtype, device=payload.device)
-    dist.all_gather_into_tensor(out, payload)
-    if any(c != mx for c in counts):
-        out = torch.cat([out[r * mx : r * mx + counts[r]] for r in range(world)], dim=0)
-    return out.view(torch.bfloat16) if local.dtype == torch.bfloat16 else out
+    if out is not None and not ragged:
+        assert out.shape == (world * mx, d) and out.dtype == local.dtype and out.is_contiguous(), "out must be [sum n_r, D], contiguous"
+        dist.all_gather_into_tensor(out.view(torch.uint8) if as_bytes else out, payload)
+        return out
+    got = torch.empty((world * mx, db), dtype=payload.dtype, device=payload.device)
+    dist.all_gather_into_tensor(got, payload)
+    if ragged:
+        got = torch.cat([got[r * mx : r * mx + counts[r]] for r in range(world)], dim=0)
+    got = got.view(torch.bfloat16) if as_bytes else got
+    if out is not None:
+        out.copy_(got)
+        return out
+    return got
+
+
+def all_gather_floats(value: float, device=None) -> list:
+    """One float per rank -> the list of all ranks' values on every rank ([value] without a process group)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    got = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(got, mine)
+    return [float(v) for v in got.cpu()]
 
 
 def all_reduce_max_float(value: float, device=None) -> float:

@@ -11,8 +11,11 @@ item that fails to load, logged, never raised (:135-137), `[None]` for a failed 
 query (:183-185).  What changes is the execution model: the reference loops one image per
 forward on one thread per GPU (:104,:208); here the decoded crops of a call are packed
 into one device buffer and go through K1 (resize/normalise/patchify) and the batched
-bf16 MFMA ViT forward in a single `mme_embed` call.  One process drives one GPU (rank =
-LOCAL_RANK); sharding a corpus across the 8 GPUs of a node is dist.py's job.
+bf16 MFMA ViT forward in `mme_embed` calls over bounded groups.  Under a launcher (LOCAL_RANK set)
+one process drives one GPU and sharding a corpus across the 8 GPUs of a node is dist.py's job;
+constructed plainly, as the reference's callers do, the embedder holds one context per visible
+GPU (`gpu_count`, embedder.py:54-65) and fans a call out `i % n_devices` on one thread per
+context (embedder.py:191-224).
 
 There is no CPU path: constructing the embedder without libmme.so or without a GPU
 raises `MmeError`.
@@ -48,6 +51,19 @@ def last_pooling(last_hidden_state, attention_mask, normalize=True):
     return reps
 
 
+def convert_to_rgb(image):
+    """What the Mllama processor does to a non-RGB image before resizing (transformers
+    image_processing_pil_mllama.py:196-211): composite over a WHITE background through RGBA, so transparent
+    areas come out white (a plain `.convert("RGB")` would expose the colour stored under the alpha)."""
+    from PIL import Image
+
+    if image.mode == "RGB":
+        return image
+    rgba = image.convert("RGBA")
+    background = Image.new("RGBA", rgba.size, (255, 255, 255))
+    return Image.alpha_composite(background, rgba).convert("RGB")
+
+
 def _load_rgb(item):
     """path | PIL.Image | uint8[h,w,3] -> contiguous uint8[h,w,3] (embedder.py:107-114)."""
     from PIL import Image
@@ -67,7 +83,7 @@ def _load_rgb(item):
     if image.size[0] > config.MAX_IMAGE_HEIGHT_AND_WIDTH or image.size[1] > config.MAX_IMAGE_HEIGHT_AND_WIDTH:
         scale = config.MAX_IMAGE_HEIGHT_AND_WIDTH / max(image.size)
         image = image.resize((int(image.size[0] * scale), int(image.size[1] * scale)), Image.LANCZOS)
-    a = np.asarray(image.convert("RGB"))
+    a = np.asarray(convert_to_rgb(image))
     if a.shape[0] == 0 or a.shape[1] == 0:
         raise ValueError("empty image")
     return np.ascontiguousarray(a)
@@ -76,38 +92,61 @@ def _load_rgb(item):
 class RegionEmbedder:
     """Drop-in for `MmE5MllamaEmbedder` on one MI355X."""
 
+    GROUP_BYTES = 1 << 30  # packed pixels per mme_embed call (pinned staging + device copy stay bounded)
+
     def __init__(self, model_name=config.DEFAULT_MODEL_NAME, device=None, gpu_count=None, *, weights=None,
-                 seed: int = 1, pool: str = "cls", chunk: int | None = None, engine: Engine | None = None):
+                 seed: int = 1, pool: str = "cls", chunk: int | None = None, engine: Engine | None = None, devices=None):
         import torch
 
         self.torch = torch
         self.model_name = model_name
-        if device is None or device == "cuda":
-            dev_index = int(os.environ.get("LOCAL_RANK", "0"))
-        elif isinstance(device, str):
+        if engine is not None:
+            dev_list = [engine.device]
+        elif devices is not None:  # explicit device indices (may repeat: several contexts on one GPU)
+            dev_list = [int(d) for d in devices]
+        elif isinstance(device, int):
+            dev_list = [device]
+        elif isinstance(device, str) and device not in ("cuda",):
             if not device.startswith("cuda"):
                 raise MmeError(f"device={device!r}: this engine is HIP only (no CPU fallback)")
-            dev_index = int(device.split(":")[1]) if ":" in device else 0
-        else:
-            dev_index = int(device)
-        if gpu_count not in (None, 1):
-            logger.info("gpu_count=%s ignored: one process drives one GPU; shard with dist.shard_range", gpu_count)
-        self.gpu_count = 1
-        self.devices = [f"cuda:{dev_index}"]
+            dev_list = [int(device.split(":")[1]) if ":" in device else 0]
+        elif "LOCAL_RANK" in os.environ:  # one process per GPU under torchrun / bench.py
+            dev_list = [int(os.environ["LOCAL_RANK"])]
+        else:  # embedder.py:54-65: gpu_count of the visible GPUs, all of them by default
+            if not torch.cuda.is_available():
+                raise MmeError("no GPU visible to torch; the embed/compare path is HIP only (no CPU fallback)")
+            available = torch.cuda.device_count()
+            n = available if gpu_count is None else max(1, min(int(gpu_count), available))
+            logger.info(f"Using {n} of {available} available GPUs")
+            dev_list = list(range(n))
+        if not dev_list:
+            raise MmeError("no device selected")
+        self.gpu_count = len(dev_list)
+        self.devices = [f"cuda:{d}" for d in dev_list]
         self.device = torch.device(self.devices[0])
-        self.engine = engine or Engine(dev_index)
-        if engine is None:
-            self.engine.load_vit(weights if weights is not None else make_vit_weights(seed))
+        if engine is not None:
+            self.engines = [engine]
+        else:
+            w = weights if weights is not None else make_vit_weights(seed)
+            self.engines = []
+            for d in dev_list:  # one context (weights + workspace) per device, as embedder.py:73-82
+                e = Engine(d)
+                e.load_vit(w)
+                self.engines.append(e)
+        self.engine = self.engines[0]
         if chunk:
-            self.engine.set_chunk(chunk)
+            for e in self.engines:
+                e.set_chunk(chunk)
         if pool not in ("cls", "last"):
             raise ValueError("pool must be 'cls' or 'last'")
         self.pool_token = 0 if pool == "cls" else 196
+        self._group_crops = 16 * config.BATCH_SIZE
 
     # -- device-resident API -------------------------------------------------------------------
-    def pack(self, arrays):
+    def pack(self, arrays, device=None):
         """list of uint8[h,w,3] -> (pix CUDA tensor, offs int64[n], hw int32[n,2])."""
         t = self.torch
+        device = self.device if device is None else device
         n = len(arrays)
         hw = np.array([a.shape[:2] for a in arrays], dtype=np.int32).reshape(n, 2)
         sizes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
@@ -115,11 +154,11 @@ class RegionEmbedder:
         if n > 1:
             offs[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
         total = int(offs[-1] + sizes[-1]) + 16 if n else 16
-        host = t.empty(total, dtype=t.uint8, pin_memory=True)
+        host = t.empty(total, dtype=t.uint8, pin_memory=t.cuda.is_available())
         hv = host.numpy()
         for a, o, s in zip(arrays, offs, sizes):
             hv[o : o + s] = a.reshape(-1)
-        return host.to(self.device, non_blocking=True), offs, hw
+        return host.to(device, non_blocking=True), offs, hw
 
     def embed_packed(self, pix, offs, hw, want_f32=True, want_bf16=True):
         """Packed crops already in HBM -> (f32 [n,768], bf16 [n,768]) CUDA tensors."""
@@ -147,42 +186,83 @@ class RegionEmbedder:
                 "num_tiles": [[int(v)] for v in nt]}
 
     # -- reference surface ------------------------------------------------------------------------
-    def get_image_embeddings(self, image_paths, is_query=False, batch_size=config.BATCH_SIZE):
-        """embedder.py:141-226: order-preserving list of float lists with None holes."""
-        if not image_paths:
-            return []
-        embeddings = [None] * len(image_paths)
-        arrays, index = [], []
+    def _embed_list(self, dev_idx, items):
+        """One context's share of a call: [(index, item)] -> [(index, list[float] | None)] (embedder.py:86-139).
 
-        def load(item):
+        The items go through in bounded groups -- at most 16 x batch_size crops and GROUP_BYTES of packed pixels per
+        `mme_embed` call -- each decoded, packed and embedded inside its own try/except: a failure (an unreadable
+        file, an out-of-memory MmeError) voids only what it touched."""
+        engine = self.engines[dev_idx]
+        device = self.torch.device(self.devices[dev_idx])
+        results = []
+
+        def load(pair):
+            i, item = pair
             try:
-                return _load_rgb(item)
+                return i, _load_rgb(item)
             except Exception as e:  # embedder.py:135-137
                 logger.error(f"Error processing image {item if isinstance(item, (str, os.PathLike)) else type(item)}: {e}")
-                return None
+                return i, None
 
-        # PNG decode is the slow part of this call (the GPU needs ~3 ms for 48 crops) and Pillow releases the
-        # GIL while decoding: decode on a small thread pool, keep the order
-        if len(image_paths) > 4:
-            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(image_paths))) as pool:
-                loaded = list(pool.map(load, image_paths))
+        def run(group):
+            if not group:
+                return
+            try:
+                pix, offs, hw = self.pack([a for _, a in group], device)
+                e32, _ = engine.embed(pix, offs, hw, self.pool_token, want_bf16=False)
+                rows = e32.cpu().tolist()
+                results.extend((i, row) for (i, _), row in zip(group, rows))
+            except Exception as e:  # embedder.py:223-224
+                logger.error(f"Error in batch processing: {e}")
+                results.extend((i, None) for i, _ in group)
+
+        step = max(1, int(self._group_crops))
+        for g0 in range(0, len(items), step):
+            part = items[g0 : g0 + step]
+            # PNG decode is the slow part of a call (the GPU needs ~3 ms for 48 crops) and Pillow releases the GIL
+            # while decoding: decode a group on a small thread pool, keep the order
+            if len(part) > 4:
+                with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(part))) as pool:
+                    loaded = list(pool.map(load, part))
+            else:
+                loaded = [load(pr) for pr in part]
+            group, nbytes = [], 0
+            for i, a in loaded:
+                if a is None:
+                    results.append((i, None))
+                    continue
+                if group and nbytes + a.nbytes > self.GROUP_BYTES:
+                    run(group)
+                    group, nbytes = [], 0
+                group.append((i, a))
+                nbytes += a.nbytes
+            run(group)
+        return results
+
+    def get_image_embeddings(self, image_paths, is_query=False, batch_size=config.BATCH_SIZE):
+        """embedder.py:141-226: order-preserving list of float lists with None holes.
+
+        Item i goes to context i % n_devices (:191-203) and every context works through its share on its own
+        thread (:208-224); a single query image takes the first context without the pool (:158-185).
+        `batch_size` keeps the reference's meaning "images per GPU per batch", except that a device pass here
+        carries 16 of the reference's one-image forwards per unit of it (256 crops at the default 16)."""
+        if not image_paths:
+            return []
+        self._group_crops = 16 * max(1, int(batch_size))
+        embeddings = [None] * len(image_paths)
+        n_dev = len(self.engines)
+        if n_dev == 1 or (len(image_paths) == 1 and is_query):
+            shares = [list(enumerate(image_paths))]
         else:
-            loaded = [load(item) for item in image_paths]
-        for i, a in enumerate(loaded):
-            if a is not None:
-                arrays.append(a)
-                index.append(i)
-        if not arrays:
-            return embeddings
-        try:
-            pix, offs, hw = self.pack(arrays)
-            e32, _ = self.embed_packed(pix, offs, hw, want_bf16=False)
-            rows = e32.cpu().tolist()
-        except MmeError as e:
-            logger.error(f"Error in batch processing: {e}")  # embedder.py:223-224
-            return embeddings
-        for i, row in zip(index, rows):
-            embeddings[i] = row
+            shares = [[(i, p) for i, p in enumerate(image_paths) if i % n_dev == d] for d in range(n_dev)]
+        if len(shares) == 1:
+            done = [self._embed_list(0, shares[0])]
+        else:
+            with ThreadPoolExecutor(max_workers=n_dev) as pool:
+                done = list(pool.map(lambda d: self._embed_list(d, shares[d]), range(n_dev)))
+        for part in done:
+            for i, row in part:
+                embeddings[i] = row
         return embeddings
 
     def embed(self, region):

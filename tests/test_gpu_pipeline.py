@@ -292,3 +292,75 @@ def test_page_matrix_pair_shards_add_up_to_the_single_gpu_matrix(embedder):
 
     with pytest.raises(MmeError):
         page_similarity_from_table(e16, area, valid, offs, names, normalise=False, engine=eng, pair_range=(0, npairs + 1))
+
+
+def test_two_contexts_in_one_process_on_two_threads_match_the_single_context(embedder, golden_dir):
+    """the reference drives one replica per device from one process, one thread each
+    (embedder.py:73-82,191-224).  Two contexts (both on device 0 here; one per GPU on a multi-GPU node) fed
+    `i % 2` from two threads must return, item for item, the bits a single context returns -- which also
+    exercises the per-(device, kernel) launch state of launch_state.hip from two threads."""
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+
+    man = _manifest(golden_dir)
+    paths = [os.path.join(golden_dir, "crops", c["file"]) for c in man["crops"]]
+    rng = np.random.default_rng(21)
+    items = list(paths) + [rng.integers(0, 256, (int(rng.integers(20, 400)), int(rng.integers(20, 400)), 3), dtype=np.uint8) for _ in range(40)]
+    items.insert(7, "/nonexistent/region.png")
+    two = RegionEmbedder(devices=[0, 0], weights=make_vit_weights(seed=1))
+    assert two.gpu_count == 2 and len(two.engines) == 2 and two.engines[0].h.value != two.engines[1].h.value
+    want = embedder.get_image_embeddings(items)
+    for batch_size in (16, 1):  # 256- and 16-crop groups
+        got = two.get_image_embeddings(items, batch_size=batch_size)
+        assert len(got) == len(items) and got[7] is None and sum(v is None for v in got) == 1
+        for a, b in zip(got, want):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert a == b  # bit-equal float lists
+    if torch.cuda.device_count() > 1:  # a context on another device of the same process
+        other = RegionEmbedder(devices=[1], weights=make_vit_weights(seed=1))
+        got = other.get_image_embeddings(items[:12])
+        assert all((a is None) == (b is None) and (a is None or a == b) for a, b in zip(got, want[:12]))
+    for e in two.engines:
+        e.close()
+
+
+def test_one_ranks_share_of_c4_end_to_end(embedder):
+    """C4 on one GPU: 8192 synthetic crops embedded (rank 3's shard of the 65 536), the gathered
+    table of 65 536 unit rows (the other 7 shards are seeded synthetic rows, as bench.py --config c4 builds them),
+    this rank's [8192 x 65536] row block of the cosine matrix -- checked on samples against the oracle."""
+    from oracle import preprocess as opre
+    from oracle import vit as ovit
+
+    eng = embedder.engine
+    n, world, rank, d = 8192, 8, 3, 768
+    crops = synthetic_crops(n, seed=0, start=rank * n)
+    dev = embedder.device
+    pix = torch.empty(n * 224 * 224 * 3 + 16, dtype=torch.uint8, device=dev)  # 16 spare bytes: the packed-crop contract
+    pix[: n * 224 * 224 * 3] = torch.from_numpy(crops.reshape(-1)).to(dev)
+    e32, e16 = eng.embed(pix, np.arange(n, dtype=np.int64) * (224 * 224 * 3), np.tile(np.array([[224, 224]], dtype=np.int32), (n, 1)), 0)
+    g = torch.Generator(device=dev).manual_seed(17)
+    table = eng.normalise_rows(torch.randn(n * world, d, generator=g, device=dev))
+    table[rank * n : (rank + 1) * n] = e16  # where the all-gather puts this rank's shard
+    sim = eng.cosine(e16, table)
+    torch.cuda.synchronize()
+    assert sim.shape == (n, n * world)
+    # embeddings of a sample of the shard vs the oracle encoder (1e-3 cosine, north_star)
+    pick = np.array([0, 1, 4095, 4096, 8190, 8191, 1234, 6789])
+    want = ovit.vit_embed(np.stack([opre.preprocess_to_patches(crops[i]) for i in pick]), make_vit_weights(seed=1))
+    got = e32[torch.from_numpy(pick).to(dev)].cpu().numpy().astype(np.float64)
+    assert np.max(1.0 - np.sum(got * want, axis=1)) <= 1e-3
+    # sampled entries of the row block vs f64 dot products of the same bf16 rows
+    rs = np.random.default_rng(5)
+    rows = np.unique(np.concatenate([rs.integers(0, n, 48), [0, n - 1, 255, 256]]))
+    cols = np.unique(np.concatenate([rs.integers(0, n * world, 2000), [0, n * world - 1, rank * n, (rank + 1) * n - 1, 65535 - 255, 65280]]))
+    A = e16[torch.from_numpy(rows).to(dev)].double()
+    Bm = table[torch.from_numpy(cols).to(dev)].double()
+    ref = (A @ Bm.T).cpu().numpy()
+    blk = sim[torch.from_numpy(rows).to(dev)][:, torch.from_numpy(cols).to(dev)].cpu().numpy()
+    assert np.abs(blk - ref).max() <= 2e-6
+    # size-independent properties of the whole block: the shard's own columns hold the symmetric self block with a
+    # unit diagonal (to bf16 rounding of the rows), and every |cosine| <= 1 + rounding
+    own = sim[:, rank * n : (rank + 1) * n]
+    assert float((own - own.T).abs().max()) == 0.0
+    assert float((torch.diagonal(own) - 1.0).abs().max()) <= 1e-2
+    assert float(sim.abs().max()) <= 1.0 + 1e-2

@@ -26,5 +26,10 @@ def main():
                   f" = sync+prologue issue {np.mean(st[ok, w, 11] / nk[ok, w]) * K / 64:5.0f} + epilogue body {np.mean(st[ok, w, 12] / nk[ok, w]) * K / 64:5.0f} + rest", flush=True)
 
 
+        clk = st[ok, 0, 13] / np.maximum(st[ok, 0, 14], 1.0) * 0.1  # GHz: shader cycles per 10 ns tick
+        print(f"{name:4s} in-kernel clock (s_memtime / s_memrealtime x 100 MHz, median over workgroups): {np.median(clk):.3f} GHz "
+              f"(min {clk.min():.3f}, max {clk.max():.3f}); kernel {np.median(st[ok, 0, 14]) / 100:.0f} us", flush=True)
+
+
 if __name__ == "__main__":
     main()
