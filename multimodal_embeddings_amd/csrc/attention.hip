@@ -20,25 +20,35 @@
 //     reads); both swizzles are applied to the DMA source address.
 //   * O^T leaves 4 consecutive head-dims per lane; v_permlane32_swap pairs the two lane halves
 //     into 16-byte stores.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int TPAD = 224;              // 7 key tiles of 32
 constexpr int ROWB = VIT_DH * 2;       // 128-byte K/V rows in LDS
 constexpr int QKV_LD = 3 * VIT_D * 2;  // 4608-byte rows of the fused QKV activation
-constexpr int KV_BYTES = TPAD * ROWB;  // 28 KiB
-constexpr int BUF_BYTES = 2 * KV_BYTES;
 constexpr int NPIECE = 25;             // 25 x 8 rows = 200 >= 197
+// NB = LDS buffers (heads in flight + 1).  Two buffers of 224 rows (7 key tiles of 32), or three of 208 rows
+// (13 P.V steps of 16 keys; the last S^T tile then reads 16 rows past its K image, into the V image of the same
+// buffer: finite bf16 bit patterns or not, those scores belong to padded keys and are replaced, never used).
+template <int NB> struct AttnGeom {
+    static constexpr int TROWS = NB == 3 ? 208 : 224;
+    static constexpr int KV_BYTES = TROWS * ROWB;
+    static constexpr int BUF_BYTES = 2 * KV_BYTES;
+    static constexpr int LDS_BYTES = NB * BUF_BYTES;
+};
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+template <int NB>
 __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int hsplit) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x (K | V)
+    constexpr int TROWS = AttnGeom<NB>::TROWS, KV_BYTES = AttnGeom<NB>::KV_BYTES, BUF_BYTES = AttnGeom<NB>::BUF_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // NB x (K | V)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // hsplit workgroups share a crop (small batches: one workgroup per crop would leave most CUs idle and
@@ -47,10 +57,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
     const int h_begin = (blockIdx.x - b * hsplit) * hpw, h_end = h_begin + hpw;
     const char* base = (const char*)qkv + (size_t)b * VIT_T * QKV_LD;
 
-    // V rows 200..223 are never written by DMA: zero them once in both buffers (P is 0 there, but
+    // V rows 200.. are never written by DMA: zero them once in every buffer (P is 0 there, but
     // 0 * garbage could be NaN).  Rows 197..199 receive clamped copies of row 196 (finite).
-    for (int i = tid; i < 2 * 24 * 8; i += 512) {
-        const int buf = i / (24 * 8), r = (i >> 3) % 24, c = i & 7;
+    constexpr int ZROWS = TROWS - 200;
+    for (int i = tid; i < NB * ZROWS * 8; i += 512) {
+        const int buf = i / (ZROWS * 8), r = (i >> 3) % ZROWS, c = i & 7;
         *(uint4*)(lds + buf * BUF_BYTES + KV_BYTES + (200 + r) * ROWB + c * 16) = make_uint4(0, 0, 0, 0);
     }
 
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 
     bf16x8 qf[4], qn[4];
     dma_head(h_begin, 0);
+    if (NB == 3 && h_begin + 1 < h_end) dma_head(h_begin + 1, 1);  // three buffers: K/V run TWO heads ahead
     if (active) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + h_begin * ROWB + ks * 32);
@@ -92,20 +104,28 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses VALU arbitration otherwise
     for (int h = h_begin; h < h_end; ++h) {
-        const int buf = (h - h_begin) & 1;
+        const int buf = NB == 3 ? (h - h_begin) % 3 : (h - h_begin) & 1;
         const char* Kl = lds + buf * BUF_BYTES;
         const char* Vl = Kl + KV_BYTES;
         // head h has landed (each wave waits for its own pieces), everybody is done with head h-1
         // (the 4 output stores of head h-1 are this wave's youngest vector-memory operations and may
         // stay in flight: vmcnt retires in order and counts stores)
-        if (h == h_begin || !active) {
+        if (!active) {
+            // the staging wave: head h has landed; with three buffers the 50 pieces of head h+1 stay in flight
+            if (NB == 3 && h + 1 < h_end) {
+                asm volatile("s_waitcnt vmcnt(50) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+        } else if (h == h_begin) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         }
         S_BARRIER();
+        if (NB == 3 && h + 2 < h_end) dma_head(h + 2, (h + 2 - h_begin) % 3);
         if (h + 1 < h_end) {
-            dma_head(h + 1, buf ^ 1);
+            if (NB == 2) dma_head(h + 1, buf ^ 1);
             if (active) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qp + (h + 1) * ROWB + ks * 32);
@@ -235,14 +255,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 
 hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    const int smem = 2 * BUF_BYTES;
-    if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197, smem); e != hipSuccess) return e;
+    // MME_ATTN_BUFS=2 restores the two-buffer form (one head of K/V in flight) for A/B runs
+    const char* nb_env = getenv("MME_ATTN_BUFS");  // read per launch: an A/B run flips it inside one process
+    const int nb = nb_env ? atoi(nb_env) : 3;
     // enough workgroups for two per CU-slot: split a crop's heads over 1, 2, 3, 4, 6 or 12 workgroups
     int hsplit = 1;
     for (int d : {1, 2, 3, 4, 6, 12}) {
         hsplit = d;
         if (B * d >= 512) break;
     }
-    hipLaunchKernelGGL(attn_fwd_t197, dim3(B * hsplit), dim3(512), smem, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit);
+    if (nb == 2) {
+        if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_fwd_t197<2>, dim3(B * hsplit), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit);
+    } else {
+        if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<3>, AttnGeom<3>::LDS_BYTES); e != hipSuccess) return e;
+        hipLaunchKernelGGL(attn_fwd_t197<3>, dim3(B * hsplit), dim3(512), AttnGeom<3>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit);
+    }
     return hipGetLastError();
 }

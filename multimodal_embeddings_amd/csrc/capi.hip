@@ -509,7 +509,7 @@ int mme_set_normalisation(mme_ctx* c, const float mean[3], const float stdv[3]) 
 
 int mme_set_gemm_variant(mme_ctx* c, int variant) {
     if (!c) return MME_E_ARG;
-    if (variant < 0 || variant > 3) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256, 2-slot ring) or 3 (256x256, 3-deep activation ring)");
+    if (variant < 0 || variant > 5) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256, 2-slot ring), 3 (256x256, 3-deep activation ring), 4 / 5 (3 with 4 / 8 of a lane's 16 stores deferred)");
     c->gemm_variant = variant;
     return MME_OK;
 }

@@ -120,10 +120,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
 }  // namespace
 
 hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
-hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s);
+hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int defer);
 
 // variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel with a 2-slot LDS ring,
-// 3 = the same with a 3-deep activation ring (all 160 KiB of LDS)
+// 3 = the same with a 3-deep activation ring (all 160 KiB of LDS), 4 / 5 = variant 3 with a quarter / half of each tile's
+// stores deferred into the next tile's first K-tile
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (variant == 0) {
@@ -132,7 +133,7 @@ hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int varia
         variant = tiles256 >= 256 ? 3 : 1;
     }
     if (variant == 2) return launch_gemm256(epilogue, g, s);
-    if (variant == 3) return launch_gemm256r(epilogue, g, s);
+    if (variant >= 3 && variant <= 5) return launch_gemm256r(epilogue, g, s, variant == 3 ? 0 : (variant == 4 ? 4 : 8));
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

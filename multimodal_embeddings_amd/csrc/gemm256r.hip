@@ -13,6 +13,7 @@
 // phases instead of one.
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "gemm_epilogue.h"
@@ -33,9 +34,22 @@ constexpr int LDS_BYTES = 3 * ASLOT + 2 * BSLOT;
 // a K-tile, the time inside the counted wait and the time between two tiles' K loops (split into group
 // sync + prologue issue, epilogue body, rest); 16 words per wave go to `stamps` (layout: mme.h,
 // mme_gemm_stamps).  No stamp executes in the product kernel.
-template <int EPI, bool STAMP = false>
+//
+// DEFER (variants 4 and 5): the output write of a 256 x 256 bf16 tile is a fixed ~8 k cycles of store ISSUE per CU
+// (~16 B/clk/CU) during which the matrix pipe idles.  With DEFER an interior tile stores only the upper half
+// of each wave tile at once; the packed lower half (8 x 16 B per lane, 32 VGPRs -- the K loop has that many
+// to spare) is issued two stores per phase inside the first K-tile of the workgroup's NEXT tile, behind
+// that phase's LDS-DMA request, where the other wave group's MFMAs cover it.  vmcnt counts stores, in order:
+// the counted wait of that K-tile leaves twelve (nine with 4 deferred stores) operations in flight instead of six.
+// NDEF = 16-byte stores per lane that are deferred (0, 4 or 8 of the 16), issued NDEF / 4 per phase of the next
+// tile's first K-tile.
+template <int EPI, bool STAMP = false, int NDEF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tiles_m, int tiles_n, int gn, int dbg,
                                                              unsigned long long* stamps = nullptr) {
+    constexpr bool DEFER = NDEF > 0;
+    constexpr int SPP = NDEF / 4;
+    static_assert(NDEF == 0 || NDEF == 4 || NDEF == 8, "NDEF");
+    static_assert(!DEFER || epi_has_fast_path<EPI>(), "DEFER needs a 16-byte fast-path epilogue");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,6 +139,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
     // a_cur / a_nx2: LDS offsets of the A ring slots of K-tiles t and t+2; b_cur / b_nxt: B ring
     int a_cur = 0, a_nx2 = 2 * ASLOT, b_cur = 0, b_nxt = BSLOT;
     bool first_tile = true;
+    // DEFER: rows 64..127 of the previous tile's wave tile, packed, and where they go (wave-uniform base)
+    uint4 pend[DEFER ? NDEF : 1];
+    bf16_t* pend_base = nullptr;
+    const int pend_lo0 = fr * (int)g.ldo + row16_col(0, fq), pend_lo1 = fr * (int)g.ldo + row16_col(2, fq);
+    auto pend_store = [&](auto idx_tag) {
+        constexpr int IDX = decltype(idx_tag)::value;  // (i - (8 - NDEF / 2)) * 2 + (jp >> 1)
+        if constexpr (DEFER && IDX < NDEF)
+            *(uint4*)(pend_base + (int64_t)(8 - NDEF / 2 + (IDX >> 1)) * 16 * g.ldo + ((IDX & 1) ? pend_lo1 : pend_lo0)) = pend[IDX];
+    };
 
     while (true) {
         const int m0 = cx.m0, n0 = cx.n0, mrem = cx.mrem, nrem = cx.nrem;
@@ -176,7 +199,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             st_prev = now;
             st_nk += nk;
         }
-        for (int t = 0; t < nk; ++t) {
+        // one K-tile; PS >= 0: also issue the pending stores of the previous tile, SPP per phase (DEFER)
+        auto ktile = [&](const int t, auto ps_tag) {
+            constexpr int PS = decltype(ps_tag)::value;
             // K-tiles t+1 / t+2 of the stream: past the end of this tile they are the next tile's first ones
             const bool nt1 = t + 1 >= nk, nt2 = t + 2 >= nk;
             const bool has1 = (!nt1 || has_next) && (dbg & 3) != 1, has2 = (!nt2 || has_next) && (dbg & 3) != 1;
@@ -189,6 +214,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             __builtin_amdgcn_sched_barrier(0);
             READ_A(a_cur, 0)
             if (has1) stage(w1, nrem1, 128, B_RING + b_nxt + HALF);
+            if constexpr (PS >= 0) {
+                pend_store(std::integral_constant<int, SPP * 0>{});
+                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 0 + 1>{});
+            }
             S_BARRIER();
             STAMP_IV(0)
             MFMA_QUAD(0, 0)
@@ -197,6 +226,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             /* q1 */
             READ_B(b_cur, 2)
             if (has2) stage(a2, mrem2, 0, a_nx2);
+            if constexpr (PS >= 0) {
+                pend_store(std::integral_constant<int, SPP * 1>{});
+                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 1 + 1>{});
+            }
             S_BARRIER();
             STAMP_IV(2)
             MFMA_QUAD(0, 2)
@@ -205,6 +238,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             /* q2 */
             READ_A(a_cur, 4)
             if (has2) stage(a2, mrem2, 128, a_nx2 + HALF);
+            if constexpr (PS >= 0) {
+                pend_store(std::integral_constant<int, SPP * 2>{});
+                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 2 + 1>{});
+            }
             S_BARRIER();
             STAMP_IV(4)
             MFMA_QUAD(4, 2)
@@ -214,11 +251,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             const unsigned long long st_w0 = st_on ? __builtin_amdgcn_s_memtime() : 0;
             if (has2) {
                 stage(w2, nrem2, 0, B_RING + b_cur);
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                // leave in flight: A(t+2) and B_lo(t+2) (six pieces) -- and the deferred stores issued among them
+                if constexpr (PS >= 0 && SPP == 2) {
+                    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                } else if constexpr (PS >= 0) {
+                    asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (st_on) st_wait += __builtin_amdgcn_s_memtime() - st_w0;
+            if constexpr (PS >= 0) {
+                pend_store(std::integral_constant<int, SPP * 3>{});
+                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 3 + 1>{});
+            }
             S_BARRIER();
             STAMP_IV(6)
             MFMA_QUAD(4, 0)
@@ -228,7 +276,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             a_nx2 = a_nx2 == 2 * ASLOT ? 0 : a_nx2 + ASLOT;
             b_cur ^= BSLOT;
             b_nxt ^= BSLOT;
+        };
+        int t_first = 0;
+        if (DEFER && pend_base != nullptr) {  // wave-uniform: the previous tile left its lower half pending
+            ktile(0, std::integral_constant<int, 0>{});
+            t_first = 1;
+            pend_base = nullptr;
         }
+        for (int t = t_first; t < nk; ++t) ktile(t, std::integral_constant<int, -1>{});
         if (wm == 0) S_BARRIER();
 
         unsigned long long st_t1 = 0;
@@ -270,7 +325,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
                         }
                 }
             } else {
-                if constexpr (epi_has_fast_path<EPI>()) epilogue_wave_128x64<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {});
+                if constexpr (DEFER) {
+                    epilogue_wave_128x64<EPI, NDEF>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {}, pend);
+                    pend_base = (bf16_t*)g.out + (int64_t)(m0 + wm * 128) * g.ldo + (n0 + wn * 64);
+                } else if constexpr (epi_has_fast_path<EPI>()) {
+                    epilogue_wave_128x64<EPI>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {});
+                }
             }
         } else if constexpr (EPI == EPI_TOPK) {
             // candidate filter: the eight row thresholds of this lane are loaded once; a (row, 16-column)
@@ -329,7 +389,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             }
         }
         if (st_on) st_body += __builtin_amdgcn_s_memtime() - st_t1;
-        if (!has_next) break;
+        if (!has_next) {
+            if constexpr (DEFER) {
+                if (pend_base != nullptr) {
+                    pend_store(std::integral_constant<int, 0>{}); pend_store(std::integral_constant<int, 1>{});
+                    pend_store(std::integral_constant<int, 2>{}); pend_store(std::integral_constant<int, 3>{});
+                    pend_store(std::integral_constant<int, 4>{}); pend_store(std::integral_constant<int, 5>{});
+                    pend_store(std::integral_constant<int, 6>{}); pend_store(std::integral_constant<int, 7>{});
+                }
+            }
+            break;
+        }
         cx = nx;
         tile = next_tile;
     }
@@ -352,10 +422,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
 #undef K_TILE
 }
 
-template <int EPI>
+template <int EPI, int DEFER = 0>
 hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     const int smem = LDS_BYTES;
-    if (hipError_t e = ensure_dynamic_lds((const void*)gemm_bf16_tn_256r<EPI>, smem); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)gemm_bf16_tn_256r<EPI, false, DEFER>, smem); e != hipSuccess) return e;
     const int tiles_m = (g.M + TM - 1) / TM, tiles_n = (g.N + TN - 1) / TN;
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
@@ -371,7 +441,8 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     int gn = gn_env > 0 ? gn_env : (int)((2400 * 1024) / ((size_t)TN * g.K * 2));
     if (gn < 3) gn = 3;
     if (gn > tiles_n) gn = tiles_n;
-    hipLaunchKernelGGL(gemm_bf16_tn_256r<EPI>, dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, gn, dbg);
+    hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI, false, DEFER>), dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, gn, dbg,
+                       (unsigned long long*)nullptr);
     return hipGetLastError();
 }
 
@@ -397,10 +468,29 @@ hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps
 
 hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
 
-hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s) {
+hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int defer) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K <= 0 || (g.K % TK) != 0) return hipErrorInvalidValue;
     if (g.K < 2 * TK) return launch_gemm256(epilogue, g, s);  // the cross-tile stream looks two K-tiles ahead
+    if (defer == 8) {
+        switch (epilogue) {
+            case EPI_BIAS: return launch256r<EPI_BIAS, 8>(g, s);
+            case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU, 8>(g, s);
+            case EPI_BIAS_RES: return launch256r<EPI_BIAS_RES, 8>(g, s);
+            case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS, 8>(g, s);
+            case EPI_LN_BIAS_GELU: return launch256r<EPI_LN_BIAS_GELU, 8>(g, s);
+            default: break;  // the other epilogues have no deferred form
+        }
+    } else if (defer == 4) {
+        switch (epilogue) {
+            case EPI_BIAS: return launch256r<EPI_BIAS, 4>(g, s);
+            case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU, 4>(g, s);
+            case EPI_BIAS_RES: return launch256r<EPI_BIAS_RES, 4>(g, s);
+            case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS, 4>(g, s);
+            case EPI_LN_BIAS_GELU: return launch256r<EPI_LN_BIAS_GELU, 4>(g, s);
+            default: break;
+        }
+    }
     switch (epilogue) {
         case EPI_BIAS: return launch256r<EPI_BIAS>(g, s);
         case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU>(g, s);

@@ -133,9 +133,11 @@ __device__ __forceinline__ int row16_col(int jp, int fq) { return ((fq & 1) ? (j
 // would wait for it), then 16 fire-and-forget 16-byte stores, which are afterwards exactly the
 // 16 youngest vector-memory operations of the wave.  Straight-line code: a branch would make the
 // compiler re-insert vmcnt(0) at every join.
-template <int EPI, class Between>
+// NDEF > 0: the last NDEF / 2 row blocks of the wave tile (i >= 8 - NDEF / 2) are not stored but returned packed in pend[];
+// the caller issues them later (gemm256r.hip, variant 4).
+template <int EPI, int NDEF = 0, class Between>
 __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&acc)[8][4], int mw, int nw, int fr, int fq,
-                                                     Between&& between) {
+                                                     Between&& between, uint4* pend = nullptr) {
     static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU,
                   "epilogue_wave_128x64: unsupported epilogue");
     constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU;
@@ -195,7 +197,12 @@ __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&
                 v0 += unpack_bf16x4(rp);
                 v1 += unpack_bf16x4(rq);
             }
-            *(uint4*)(outb + (int64_t)i * 16 * g.ldo + (jp ? lo1 : lo0)) = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
+            const uint4 packed = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
+            if (NDEF > 0 && i >= 8 - NDEF / 2) {
+                pend[(i - (8 - NDEF / 2)) * 2 + (jp >> 1)] = packed;
+            } else {
+                *(uint4*)(outb + (int64_t)i * 16 * g.ldo + (jp ? lo1 : lo0)) = packed;
+            }
         }
     }
 }

@@ -232,7 +232,7 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
     pix, offs, hw = _pack(arrays)
     engine.set_gemm_variant(1)
     e1, _ = engine.embed(pix, offs, hw)
-    for variant in (2, 3):
+    for variant in (2, 3, 4, 5):  # 4 / 5: a quarter / half of each tile's stores deferred into the next tile's K loop
         engine.set_gemm_variant(variant)
         for _ in range(3):
             e2, _ = engine.embed(pix, offs, hw)
@@ -242,11 +242,19 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
     pixb, offsb, hwb = _pack(list(crops))
     engine.set_gemm_variant(1)
     r1, _ = engine.embed(pixb, offsb, hwb)
-    for variant in (2, 3):
+    for variant in (2, 3, 4, 5):
         engine.set_gemm_variant(variant)
-        r2, _ = engine.embed(pixb, offsb, hwb)
-        assert torch.equal(r1, r2), variant
+        for _ in range(2):
+            r2, _ = engine.embed(pixb, offsb, hwb)
+            assert torch.equal(r1, r2), variant
     engine.set_gemm_variant(0)
+    # the attention kernel with two LDS buffers (one head of K/V in flight) and with three (two heads) agree bit for bit
+    os.environ["MME_ATTN_BUFS"] = "2"
+    try:
+        r3, _ = engine.embed(pixb, offsb, hwb)
+    finally:
+        del os.environ["MME_ATTN_BUFS"]
+    assert torch.equal(r1, r3)
 
 
 def test_cross_compare_api(engine):
