@@ -86,15 +86,20 @@ int mme_set_normalisation(mme_ctx* ctx, const float mean[3], const float std[3])
 int mme_set_chunk(mme_ctx* ctx, int crops_per_pass);
 
 /* Tuning / test knob: which MFMA GEMM tiling serves K2/K4/K6/K7/K9.  0 = by shape (default),
- * 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel with a 2-slot LDS ring, 3 = the same with a
- * 3-deep activation ring (the default for large problems).  Results are bit-identical across variants
- * (same MFMA instruction, same K order per output element). */
+ * 1 = 128x128 tiles, 3 = 256x256 ping-pong kernel with a 3-deep activation ring (2 is accepted and
+ * means 3), 4 / 6 / 5 = variant 3 with 4 / 6 / 8 of a lane's 16 output stores deferred into the next
+ * tile's first K-tile (4 is the default for large problems).  Results are bit-identical across
+ * variants (same MFMA instruction, same K order per output element). */
 int mme_set_gemm_variant(mme_ctx* ctx, int variant);
 
-/* LayerNorm folding (default on): LN1 / LN2 are folded into the QKV / fc1 GEMMs
- * (W' = W*gamma, out = rstd*(W'x - mean*colsum) + b'), so the residual stream is read once per
- * LayerNorm and no normalised copy is written.  0 = separate LayerNorm kernel (A/B, tests). */
-int mme_set_ln_fusion(mme_ctx* ctx, int on);
+/* LayerNorm folding: LN1 / LN2 are folded into the QKV / fc1 GEMMs
+ * (W' = W*gamma, out = rstd*(W'x - mean*colsum) + b'), so no normalised copy is written.
+ *   2 (default) the per-row statistics come from partial sums the GEMM that wrote the residual
+ *     stream left behind (96 bytes per row to finish; the stream is not read again);
+ *   1 one statistics pass over the residual stream per LayerNorm, same canonical summation order
+ *     (bit-identical embeddings to mode 2);
+ *   0 separate LayerNorm kernel (A/B, tests). */
+int mme_set_ln_fusion(mme_ctx* ctx, int mode);
 
 /* ---- K0: cut the bounding boxes of one decoded page on the device ----------
  * Replaces DocLayoutDetector.get_region_image (doclayout_detector.py:165-194), which re-opens
@@ -245,6 +250,13 @@ int mme_gemm_bench(mme_ctx* ctx, int M, int N, int K, int epilogue, int variant,
  * next tile's first K-tile; [13] s_memtime cycles and [14] s_memrealtime ticks (100 MHz) of the whole kernel:
  * [13] / [14] x 100 MHz is the clock the chip held (the call runs ~0.5 s of the product kernel first). */
 int mme_gemm_stamps(mme_ctx* ctx, int M, int N, int K, uint64_t* stamps_host);
+
+/* Diagnostic: time the attention kernel (K5) on B crops of random activations (avg_ms over iters launches), then run
+ * its stamped build once.  stamps_host uint64[B workgroups][8 waves][8]: s_memtime cycles summed over the 12 head
+ * iterations of the wave -- [0] wait for its own requests, [1] workgroup barrier, [2] issue of the next head's
+ * requests (K/V LDS-DMA on wave 7, Q prefetch on the others), [3] S^T = K.Q^T, [4] softmax, [5] O^T = V^T.P^T,
+ * [6] hand-over + output stores; [7] heads processed. */
+int mme_attention_stamps(mme_ctx* ctx, int B, int iters, double* avg_ms, uint64_t* stamps_host);
 
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
  * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster,

@@ -67,6 +67,7 @@ EXPORTS = {
     "mme_set_neighbour_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mme_gemm_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mme_attention_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
     "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
@@ -180,8 +181,10 @@ class Engine:
     def set_gemm_variant(self, variant: int):
         self._check(self.lib.mme_set_gemm_variant(self.h, int(variant)), "mme_set_gemm_variant")
 
-    def set_ln_fusion(self, on: bool):
-        self._check(self.lib.mme_set_ln_fusion(self.h, int(bool(on))), "mme_set_ln_fusion")
+    def set_ln_fusion(self, mode):
+        """0 / False: LayerNorm kernel; 1: folded + statistics pass over x; 2 / True: folded + partial sums from the producing GEMM."""
+        m = 2 if mode is True else int(mode)
+        self._check(self.lib.mme_set_ln_fusion(self.h, m), "mme_set_ln_fusion")
 
     def set_chunk(self, crops: int):
         self._check(self.lib.mme_set_chunk(self.h, int(crops)), "mme_set_chunk")
@@ -358,6 +361,13 @@ class Engine:
         st = np.zeros((256, 2, 16), dtype=np.uint64)
         self._check(self.lib.mme_gemm_stamps(self.h, M, N, K, st.ctypes.data), "mme_gemm_stamps")
         return st
+
+    def attention_stamps(self, B, iters=5):
+        """(avg ms of the product kernel, uint64[B, 8, 8] cycle stamps of the stamped build; see mme.h)."""
+        st = np.zeros((B, 8, 8), dtype=np.uint64)
+        ms = C.c_double(0)
+        self._check(self.lib.mme_attention_stamps(self.h, int(B), int(iters), C.byref(ms), st.ctypes.data), "mme_attention_stamps")
+        return ms.value, st
 
     # ---- timing ------------------------------------------------------------------------------------
     def profile(self, on: bool):

@@ -21,6 +21,7 @@
 //   * O^T leaves 4 consecutive head-dims per lane; v_permlane32_swap pairs the two lane halves
 //     into 16-byte stores.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -45,8 +46,13 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int NB>
-__global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int hsplit) {
+// STAMP: diagnostic build -- every wave accumulates s_memtime intervals between seven points of a head
+// iteration (wait, barrier, request issue, S^T, softmax, P.V, stores) and writes 8 words per wave to `stamps`
+// (layout: mme.h, mme_attention_stamps).  No stamp executes in the product kernel.
+// PIPE: the softmax rides inside the MFMA loops (default); false = the phase-by-phase form it replaced (A/B).
+template <int NB, bool STAMP = false, bool PIPE = true>
+__global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int hsplit,
+                                                         unsigned long long* stamps = nullptr) {
     constexpr int TROWS = AttnGeom<NB>::TROWS, KV_BYTES = AttnGeom<NB>::KV_BYTES, BUF_BYTES = AttnGeom<NB>::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) char lds[];  // NB x (K | V)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -102,6 +108,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + h_begin * ROWB + ks * 32);
     }
 
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
+#define ATTN_STAMP(i)                                                \
+    if (STAMP) {                                                     \
+        const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+        st[i] += now - st_prev;                                      \
+        st_prev = now;                                               \
+    }
+    if (STAMP) st_prev = __builtin_amdgcn_s_memtime();
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses VALU arbitration otherwise
     for (int h = h_begin; h < h_end; ++h) {
         const int buf = NB == 3 ? (h - h_begin) % 3 : (h - h_begin) & 1;
@@ -122,7 +136,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         } else {
             asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         }
+        ATTN_STAMP(0)  // own requests landed
         S_BARRIER();
+        ATTN_STAMP(1)  // everybody's
         if (NB == 3 && h + 2 < h_end) dma_head(h + 2, (h + 2 - h_begin) % 3);
         if (h + 1 < h_end) {
             if (NB == 2) dma_head(h + 1, buf ^ 1);
@@ -131,8 +147,106 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                 for (int ks = 0; ks < 4; ++ks) qn[ks] = *(const bf16x8*)(qp + (h + 1) * ROWB + ks * 32);
             }
         }
+        ATTN_STAMP(2)  // next head's requests issued
         if (active) {
             f32x16 s[7];
+            float inv;
+            f32x16 o[2];
+            s16x8 vf[2][2];
+            auto read_v = [&](int i, s16x8 (&dst)[2]) {
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* va = Vl + i * 16 * ROWB + (db ? v_off1 : v_off0);
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * ROWB));
+                    dst[db] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            };
+            if constexpr (PIPE) {
+                // The kernel is bound by vector-ALU and matrix issue per SIMD, not by HBM (stamped build: a wave's
+                // S^T, softmax and P.V phases ran back to back and its SIMD partner's did not overlap them).  Here
+                // the softmax rides inside the two MFMA loops of the SAME wave: the running maximum of tile kt - 1
+                // is taken while the four MFMAs of tile kt execute, and the exponentials / bf16 conversion of
+                // P.V step i + 1 are computed between the two MFMAs of step i.
+                bf16x8 kf[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[0][ks] = *(const bf16x8*)(Kl + r * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                float mx = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+                for (int kt = 0; kt < 7; ++kt) {
+                    if (kt + 1 < 7) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            kf[(kt + 1) & 1][ks] = *(const bf16x8*)(Kl + ((kt + 1) * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                    }
+                    f32x16 a;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt & 1][ks], qf[ks], a, 0, 0, 0);
+                    s[kt] = a;
+                    if (kt >= 1) {
+#pragma unroll
+                        for (int e = 0; e < 16; e += 4) {
+                            mx = fmaxf(fmaxf(mx, s[kt - 1][e]), s[kt - 1][e + 1]);
+                            mx1 = fmaxf(fmaxf(mx1, s[kt - 1][e + 2]), s[kt - 1][e + 3]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                ATTN_STAMP(3)  // S^T (+ running maximum)
+#pragma unroll
+                for (int e = 0; e < 16; e += 4) {
+                    mx = fmaxf(fmaxf(mx, s[5][e]), s[5][e + 1]);
+                    mx1 = fmaxf(fmaxf(mx1, s[5][e + 2]), s[5][e + 3]);
+                }
+                mx = fmaxf(mx, mx1);
+                // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding: of the last
+                // tile only e = 0..3 can be valid (keys 192..195 in the lower lane half, 196 in the upper)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e + 4 * hh < VIT_T - 192) mx = fmaxf(mx, s[6][e]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float nmx = -mx * sc;
+                float sum4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains: a single one serialises 104 dependent adds
+                // P of step i (16 keys: 8 values per lane), exponentiated, summed and rounded to bf16
+                auto soft = [&](auto i_tag, bf16x8& pf) {
+                    constexpr int I = decltype(i_tag)::value;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        constexpr int kt = I >> 1;
+                        const int e = 8 * (I & 1) + j;
+                        float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][e], sc, nmx));
+                        if (kt == 6 && !(e < 4 && e + 4 * hh < VIT_T - 192)) pv = 0.f;
+                        sum4[j & 3] += pv;
+                        pf[j] = (bf16_t)pv;
+                    }
+                };
+                ATTN_STAMP(4)  // maximum
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
+                bf16x8 pf[2];
+                read_v(0, vf[0]);
+                soft(std::integral_constant<int, 0>{}, pf[0]);
+                auto pv_step = [&](auto i_tag) {
+                    constexpr int I = decltype(i_tag)::value;
+                    if (I + 1 < 13) read_v(I + 1, vf[(I + 1) & 1]);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[I & 1][0]), pf[I & 1], o[0], 0, 0, 0);
+                    if constexpr (I + 1 < 13) soft(std::integral_constant<int, (I + 1 < 13 ? I + 1 : 0)>{}, pf[(I + 1) & 1]);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[I & 1][1]), pf[I & 1], o[1], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                pv_step(std::integral_constant<int, 0>{}); pv_step(std::integral_constant<int, 1>{});
+                pv_step(std::integral_constant<int, 2>{}); pv_step(std::integral_constant<int, 3>{});
+                pv_step(std::integral_constant<int, 4>{}); pv_step(std::integral_constant<int, 5>{});
+                pv_step(std::integral_constant<int, 6>{}); pv_step(std::integral_constant<int, 7>{});
+                pv_step(std::integral_constant<int, 8>{}); pv_step(std::integral_constant<int, 9>{});
+                pv_step(std::integral_constant<int, 10>{}); pv_step(std::integral_constant<int, 11>{});
+                pv_step(std::integral_constant<int, 12>{});
+                float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+                sum += __shfl_xor(sum, 32, 64);
+                inv = __builtin_amdgcn_rcpf(sum);
+            } else {
             // S^T tiles; the K fragments of tile kt+1 are requested before the MFMAs of tile kt so
             // that no MFMA waits on the ds_read issued just before it
             bf16x8 kf[2][4];
@@ -153,6 +267,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                 s[kt] = a;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            ATTN_STAMP(3)  // S^T
             // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding: of the last
             // tile only e = 0..3 can be valid (keys 192..195 in the lower lane half, 196 in the upper)
             float mx = -INFINITY;
@@ -190,23 +305,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
             for (int e = 4; e < 16; ++e) s[6][e] = 0.f;
             float sum = sum2.x + sum2.y;
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = __builtin_amdgcn_rcpf(sum);
+            inv = __builtin_amdgcn_rcpf(sum);
 
-            f32x16 o[2];
+            ATTN_STAMP(4)  // softmax
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[0][e] = o[1][e] = 0.f;
             // 13 steps of 16 keys (keys 208..223 are all padding); the V^T fragments of step i+1 are
             // requested before the MFMAs of step i
-            s16x8 vf[2][2];
-            auto read_v = [&](int i, s16x8 (&dst)[2]) {
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    const char* va = Vl + i * 16 * ROWB + (db ? v_off1 : v_off0);
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * ROWB));
-                    dst[db] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                }
-            };
             read_v(0, vf[0]);
 #pragma unroll
             for (int i = 0; i < 13; ++i) {
@@ -219,6 +324,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[i & 1][db]), pf, o[db], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
+            ATTN_STAMP(5)  // P.V
             if (h + 1 < h_end) {  // before the stores: the wait for the prefetched Q must not cover them
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) qf[ks] = qn[ks];
@@ -247,29 +354,54 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                     const uint4 w = make_uint4(ax[0], ay[0], ax[1], ay[1]);
                     if (q < VIT_T) *(uint4*)(op + db * 32 + (rp + hh) * 8) = w;
                 }
+            ATTN_STAMP(6)  // Q hand-over + stores issued
         }
     }
+    if (STAMP && lane == 0 && stamps) {
+        unsigned long long* o = stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) o[i] = st[i];
+        o[7] = (unsigned long long)(h_end - h_begin);
+    }
+#undef ATTN_STAMP
 }
 
 }  // namespace
 
 hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    // MME_ATTN_BUFS=2 restores the two-buffer form (one head of K/V in flight) for A/B runs
+    // MME_ATTN_BUFS=3: three K/V buffers (two heads in flight); measured 3 % slower than two, kept for A/B runs
     const char* nb_env = getenv("MME_ATTN_BUFS");  // read per launch: an A/B run flips it inside one process
-    const int nb = nb_env ? atoi(nb_env) : 3;
+    const int nb = nb_env ? atoi(nb_env) : 2;
     // enough workgroups for two per CU-slot: split a crop's heads over 1, 2, 3, 4, 6 or 12 workgroups
     int hsplit = 1;
     for (int d : {1, 2, 3, 4, 6, 12}) {
         hsplit = d;
         if (B * d >= 512) break;
     }
+    const char* pipe_env = getenv("MME_ATTN_PIPE");
+    if (pipe_env && atoi(pipe_env) == 0) {  // the phase-by-phase softmax (A/B)
+        if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2, false, false>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
+        hipLaunchKernelGGL((attn_fwd_t197<2, false, false>), dim3(B * hsplit), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit,
+                           (unsigned long long*)nullptr);
+        return hipGetLastError();
+    }
     if (nb == 2) {
         if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_fwd_t197<2>, dim3(B * hsplit), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit);
+        hipLaunchKernelGGL((attn_fwd_t197<2>), dim3(B * hsplit), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit,
+                           (unsigned long long*)nullptr);
     } else {
         if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<3>, AttnGeom<3>::LDS_BYTES); e != hipSuccess) return e;
-        hipLaunchKernelGGL(attn_fwd_t197<3>, dim3(B * hsplit), dim3(512), AttnGeom<3>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit);
+        hipLaunchKernelGGL((attn_fwd_t197<3>), dim3(B * hsplit), dim3(512), AttnGeom<3>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit,
+                           (unsigned long long*)nullptr);
     }
+    return hipGetLastError();
+}
+
+// diagnostic: the stamped build (two buffers, one workgroup per crop); stamps = uint64[B][8 waves][8], zeroed by the caller
+hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2, true>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
+    hipLaunchKernelGGL((attn_fwd_t197<2, true>), dim3(B), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, 1, stamps);
     return hipGetLastError();
 }

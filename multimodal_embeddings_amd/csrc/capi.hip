@@ -49,7 +49,7 @@ struct mme_ctx {
     float ln_eps = 1e-12f;
     int chunk = 4096;
     int gemm_variant = 0;
-    bool fuse_ln = true;
+    int ln_mode = 2;  // 0 LayerNorm kernel, 1 folded into the GEMMs + one statistics pass over x, 2 folded + partial sums from the producing epilogue
     int neigh_mode = 0;  // K12: 0 by size, 1 cosine block through the workspace, 2 fused candidate lists
     // weights
     std::vector<void*> allocs;
@@ -59,7 +59,7 @@ struct mme_ctx {
     float* lut = nullptr;  // [3,256]
     // workspace (sized for `chunk` crops)
     int ws_chunk = 0;
-    DevBuf x, hbuf, qkv, att, mlp, stats, patches, tmp, crops, hwork, page_ws, cluster_ws, neigh_ws;
+    DevBuf x, hbuf, qkv, att, mlp, stats, lnpart, patches, tmp, crops, hwork, page_ws, cluster_ws, neigh_ws;
     // host staging for crop tables
     std::vector<CropDesc> h_crops;
     std::vector<HWork> h_work;
@@ -192,6 +192,7 @@ int ensure_workspace(mme_ctx* c) {
     if ((r = ensure(c, c->att, rows * VIT_D * 2))) return r;
     if ((r = ensure(c, c->mlp, rows * VIT_F * 2))) return r;
     if ((r = ensure(c, c->stats, rows * 2 * sizeof(float)))) return r;
+    if ((r = ensure(c, c->lnpart, rows * 2 * (VIT_D / 64) * sizeof(float)))) return r;
     c->ws_chunk = c->chunk;
     return MME_OK;
 }
@@ -253,13 +254,30 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
         Timed t(c, s, KC_LN);
         HIP_TRY(c, launch_cls_rows(c->x.p, c->cls, c->pos, n, s));
     }
+    // LayerNorm statistics of the residual stream x for the GEMM that folds the LayerNorm in.  Mode 2: the GEMM
+    // that WROTE x (EPI_BIAS_RES_STATS) left per-slice partial sums; finishing them reads 96 bytes per row
+    // instead of the 1536-byte row.  Rows of a ragged last row tile, launches that ran the 128 x 128 kernel and
+    // the first LayerNorm of the pass take the stand-alone kernel, which sums in the same canonical order.
+    auto stats_from_x = [&](int64_t row0) -> int {
+        Timed t(c, s, KC_LN);
+        HIP_TRY(c, launch_ln_stats_canonical(c->x.p, row0, M, VIT_D, c->ln_eps, (float*)c->stats.p, s));
+        return MME_OK;
+    };
+    auto stats_after = [&](const GemmArgs& producer) -> int {
+        if (c->ln_mode != 2 || !gemm_runs_256(producer, c->gemm_variant)) return stats_from_x(0);
+        const int64_t interior = (int64_t)(M / 256) * 256;
+        {
+            Timed t(c, s, KC_LN);
+            HIP_TRY(c, launch_ln_finish((const float*)c->lnpart.p, producer.ln_part_rows, interior, VIT_D, c->ln_eps, (float*)c->stats.p, s));
+        }
+        return interior < M ? stats_from_x(interior) : MME_OK;
+    };
+    const int res_epi = c->ln_mode == 2 ? EPI_BIAS_RES_STATS : EPI_BIAS_RES;
+    int r;
+    if (c->ln_mode != 0 && (r = stats_from_x(0))) return r;
     for (int l = 0; l < VIT_L; ++l) {
         const LayerDev& L = c->layer[l];
-        if (c->fuse_ln) {  // LN1 folded into the QKV GEMM: x is read once, nothing normalised is written
-            {
-                Timed t(c, s, KC_LN);
-                HIP_TRY(c, launch_ln_stats(c->x.p, M, c->ln_eps, (float*)c->stats.p, s));
-            }
+        if (c->ln_mode != 0) {  // LN1 folded into the QKV GEMM: x is read once, nothing normalised is written
             Timed t(c, s, KC_GEMM);
             g = GemmArgs{};
             g.A = c->x.p; g.W = L.qkv_wf; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
@@ -285,13 +303,11 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->att.p; g.W = L.o_w; g.M = M; g.N = VIT_D; g.K = VIT_D;
             g.bias = L.o_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
-            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
+            g.ln_part = (float*)c->lnpart.p; g.ln_part_rows = (int64_t)c->ws_chunk * VIT_T;
+            HIP_TRY(c, launch_gemm(res_epi, g, s, c->gemm_variant));
         }
-        if (c->fuse_ln) {
-            {
-                Timed t(c, s, KC_LN);
-                HIP_TRY(c, launch_ln_stats(c->x.p, M, c->ln_eps, (float*)c->stats.p, s));
-            }
+        if (c->ln_mode != 0) {
+            if ((r = stats_after(g))) return r;
             Timed t(c, s, KC_GEMM);
             g = GemmArgs{};
             g.A = c->x.p; g.W = L.fc1_wf; g.M = M; g.N = VIT_F; g.K = VIT_D;
@@ -308,13 +324,16 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g.bias = L.fc1_b; g.out = c->mlp.p; g.ldo = VIT_F;
             HIP_TRY(c, launch_gemm(EPI_BIAS_GELU, g, s, c->gemm_variant));
         }
+        const bool last = l + 1 == VIT_L;  // the final LayerNorm touches the pooled row only (K8)
         {
             Timed t(c, s, KC_GEMM);
             g = GemmArgs{};
             g.A = c->mlp.p; g.W = L.fc2_w; g.M = M; g.N = VIT_D; g.K = VIT_F;
             g.bias = L.fc2_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
-            HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
+            g.ln_part = (float*)c->lnpart.p; g.ln_part_rows = (int64_t)c->ws_chunk * VIT_T;
+            HIP_TRY(c, launch_gemm(last ? EPI_BIAS_RES : res_epi, g, s, c->gemm_variant));
         }
+        if (c->ln_mode != 0 && !last && (r = stats_after(g))) return r;
     }
     {
         Timed t(c, s, KC_POOL);
@@ -427,7 +446,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->neigh_ws};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -509,14 +528,15 @@ int mme_set_normalisation(mme_ctx* c, const float mean[3], const float stdv[3]) 
 
 int mme_set_gemm_variant(mme_ctx* c, int variant) {
     if (!c) return MME_E_ARG;
-    if (variant < 0 || variant > 5) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256, 2-slot ring), 3 (256x256, 3-deep activation ring), 4 / 5 (3 with 4 / 8 of a lane's 16 stores deferred)");
+    if (variant < 0 || variant > 6) return fail(c, MME_E_ARG, "mme_set_gemm_variant: 0 (auto), 1 (128x128), 2 (256x256, 2-slot ring), 3 (256x256, 3-deep activation ring), 4 / 5 (3 with 4 / 8 of a lane's 16 stores deferred)");
     c->gemm_variant = variant;
     return MME_OK;
 }
 
-int mme_set_ln_fusion(mme_ctx* c, int on) {
+int mme_set_ln_fusion(mme_ctx* c, int mode) {
     if (!c) return MME_E_ARG;
-    c->fuse_ln = on != 0;
+    if (mode < 0 || mode > 2) return fail(c, MME_E_ARG, "mme_set_ln_fusion: 0 (LayerNorm kernel), 1 (folded, statistics pass over x) or 2 (folded, partial sums from the producing GEMM)");
+    c->ln_mode = mode;
     return MME_OK;
 }
 
@@ -1013,6 +1033,47 @@ int mme_gemm_stamps(mme_ctx* c, int M, int N, int K, uint64_t* stamps_host) {
     // ~0.5 s of back-to-back launches of the product kernel first: the clock stamps ([13], [14]) are only
     // meaningful once DVFS has settled under this load
     return gemm_bench_impl(c, M, N, K, EPI_BIAS, 3, 150, &ms, stamps_host);
+}
+
+int mme_attention_stamps(mme_ctx* c, int B, int iters, double* avg_ms, uint64_t* stamps_host) {
+    if (!c || !avg_ms || !stamps_host || B <= 0 || iters < 1) return fail(c, MME_E_ARG, "mme_attention_stamps: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t rows = (size_t)B * VIT_T, q_bytes = rows * 3 * VIT_D * 2, o_bytes = rows * VIT_D * 2, st_bytes = (size_t)B * 64 * sizeof(uint64_t);
+    void *Q = nullptr, *O = nullptr, *ST = nullptr;
+    int rc = MME_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    do {
+        if (hipMalloc(&Q, q_bytes) != hipSuccess || hipMalloc(&O, o_bytes) != hipSuccess || hipMalloc(&ST, st_bytes) != hipSuccess) { rc = fail(c, MME_E_NOMEM, "mme_attention_stamps: hipMalloc"); break; }
+        {   // uniform [-1, 1) bf16 activations, a 64 MB pattern repeated
+            const size_t pat = (size_t)32 << 20;
+            std::vector<uint16_t> h(pat);
+            uint64_t x = 0x9E3779B97F4A7C15ull;
+            for (size_t i = 0; i < pat; ++i) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                h[i] = f32_to_bf16_rne((float)((int64_t)(x >> 40) - (1 << 23)) * (1.0f / (1 << 23)));
+            }
+            for (size_t o = 0; o < q_bytes; o += pat * 2)
+                if (hipMemcpy((char*)Q + o, h.data(), (q_bytes - o < pat * 2 ? q_bytes - o : pat * 2), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, MME_E_HIP, "memcpy"); break; }
+            if (rc) break;
+        }
+        hipStream_t s = nullptr;
+        if (launch_attention(Q, O, B, s) != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_attention_stamps: launch"); break; }
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) (void)launch_attention(Q, O, B, s);
+        (void)hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_attention_stamps: kernel failed"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+        (void)hipMemset(ST, 0, st_bytes);
+        if (launch_attention_stamped(Q, O, B, (unsigned long long*)ST, s) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_attention_stamps: stamped launch"); break; }
+        (void)hipMemcpy(stamps_host, ST, st_bytes, hipMemcpyDeviceToHost);
+    } while (0);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    for (void* p : {Q, O, ST}) if (p) (void)hipFree(p);
+    return rc;
 }
 
 int mme_profile_enable(mme_ctx* c, int on) {

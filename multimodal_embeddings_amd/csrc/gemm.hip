@@ -119,28 +119,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_128(GemmArgs g) {
 
 }  // namespace
 
-hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
 hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int defer);
 
-// variant: 0 = choose by shape, 1 = 128x128 tiles, 2 = 256x256 ping-pong kernel with a 2-slot LDS ring,
-// 3 = the same with a 3-deep activation ring (all 160 KiB of LDS), 4 / 5 = variant 3 with a quarter / half of each tile's
-// stores deferred into the next tile's first K-tile
-hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
-    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+// variant: 0 = choose by shape, 1 = 128x128 tiles, 3 = 256x256 ping-pong kernel with a 3-deep activation ring (all 160 KiB
+// of LDS), 4 / 6 / 5 = variant 3 with 4 / 6 / 8 of a lane's 16 stores deferred into the next tile's first K-tile (2 is
+// accepted for old callers and means 3: the 2-slot-ring kernel it named was folded into gemm256r.hip)
+static int resolve_variant(const GemmArgs& g, int variant) {
     if (variant == 0) {
         // the 256 kernel wants at least ~2 tiles per CU to amortise its prologue
         const int64_t tiles256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256);
-        variant = tiles256 >= 256 ? 3 : 1;
+        variant = tiles256 >= 256 ? 4 : 1;
     }
-    if (variant == 2) return launch_gemm256(epilogue, g, s);
-    if (variant >= 3 && variant <= 5) return launch_gemm256r(epilogue, g, s, variant == 3 ? 0 : (variant == 4 ? 4 : 8));
+    if (variant == 2) variant = 3;
+    if (g.K < 128) variant = 1;  // the 256 kernel streams two K-tiles ahead
+    return variant;
+}
+
+bool gemm_runs_256(const GemmArgs& g, int variant) { return resolve_variant(g, variant) != 1; }
+
+hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    variant = resolve_variant(g, variant);
+    if (variant >= 3 && variant <= 6) return launch_gemm256r(epilogue, g, s, variant == 3 ? 0 : (variant == 4 ? 4 : (variant == 5 ? 8 : 6)));
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);
     switch (epilogue) {
         case EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS>, grid, block, 0, s, g); break;
         case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS_GELU>, grid, block, 0, s, g); break;
-        case EPI_BIAS_RES: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS_RES>, grid, block, 0, s, g); break;
+        case EPI_BIAS_RES:
+        case EPI_BIAS_RES_STATS:  // no partial planes from this kernel: the caller derives the statistics from x (gemm_runs_256)
+            hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_BIAS_RES>, grid, block, 0, s, g); break;
         case EPI_PATCH: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_PATCH>, grid, block, 0, s, g); break;
         case EPI_F32: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_F32>, grid, block, 0, s, g); break;
         case EPI_LN_BIAS: hipLaunchKernelGGL(gemm_bf16_tn_128<EPI_LN_BIAS>, grid, block, 0, s, g); break;

@@ -1,7 +1,7 @@
 // bf16 "TN" GEMM, 256 x 256 x 64 tile, 8 waves, THREE-deep activation ring (variant 3, the default for large problems).
 //
-// Same wave layout, ping-pong phases, LDS image and epilogues as gemm256.hip; what changes is
-// the staging schedule.  All 160 KiB of LDS are used: a 3-slot ring for the A (activation)
+// 8 waves as 2 x 4 (wave tile 128 x 64), two wave groups one barrier apart (ping-pong), XOR-swizzled
+// 128-byte LDS rows filled by LDS-DMA, epilogues of gemm_epilogue.h.  Staging schedule:  All 160 KiB of LDS are used: a 3-slot ring for the A (activation)
 // half tiles and a 2-slot ring for the B (weight) half tiles.  A comes from HBM / Infinity
 // Cache (an L2 miss costs well over a K-tile of time under load), B is L2 resident, so A is
 // requested TWO K-tiles ahead and B one (across output tiles: the stream of K-tiles of a workgroup's
@@ -38,17 +38,16 @@ constexpr int LDS_BYTES = 3 * ASLOT + 2 * BSLOT;
 // DEFER (variants 4 and 5): the output write of a 256 x 256 bf16 tile is a fixed ~8 k cycles of store ISSUE per CU
 // (~16 B/clk/CU) during which the matrix pipe idles.  With DEFER an interior tile stores only the upper half
 // of each wave tile at once; the packed lower half (8 x 16 B per lane, 32 VGPRs -- the K loop has that many
-// to spare) is issued two stores per phase inside the first K-tile of the workgroup's NEXT tile, behind
+// to spare) is issued one store per phase inside the first K-tiles of the workgroup's NEXT tile, behind
 // that phase's LDS-DMA request, where the other wave group's MFMAs cover it.  vmcnt counts stores, in order:
-// the counted wait of that K-tile leaves twelve (nine with 4 deferred stores) operations in flight instead of six.
-// NDEF = 16-byte stores per lane that are deferred (0, 4 or 8 of the 16), issued NDEF / 4 per phase of the next
-// tile's first K-tile.
+// the counted wait of such a K-tile leaves nine operations in flight instead of six.
+// NDEF = 16-byte stores per lane that are deferred (0, 4, 6 or 8 of the 16), issued one or two per phase of the
+// next tile's first K-tile.
 template <int EPI, bool STAMP = false, int NDEF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tiles_m, int tiles_n, int gn, int dbg,
                                                              unsigned long long* stamps = nullptr) {
     constexpr bool DEFER = NDEF > 0;
-    constexpr int SPP = NDEF / 4;
-    static_assert(NDEF == 0 || NDEF == 4 || NDEF == 8, "NDEF");
+        static_assert(NDEF == 0 || NDEF == 4 || NDEF == 6 || NDEF == 8, "NDEF");
     static_assert(!DEFER || epi_has_fast_path<EPI>(), "DEFER needs a 16-byte fast-path epilogue");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,6 +147,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         if constexpr (DEFER && IDX < NDEF)
             *(uint4*)(pend_base + (int64_t)(8 - NDEF / 2 + (IDX >> 1)) * 16 * g.ldo + ((IDX & 1) ? pend_lo1 : pend_lo0)) = pend[IDX];
     };
+    // pending stores issued in phase q of the carrying K-tile: 4 -> 1,1,1,1   6 -> 2,2,1,1   8 -> 2,2,2,2
+    constexpr int PQ0 = NDEF >= 6 ? 2 : 1, PQ1 = NDEF >= 6 ? 2 : 1, PQ2 = NDEF >= 8 ? 2 : 1;
+    constexpr int PQ_BEFORE_WAIT = PQ0 + PQ1 + PQ2;
 
     while (true) {
         const int m0 = cx.m0, n0 = cx.n0, mrem = cx.mrem, nrem = cx.nrem;
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             st_prev = now;
             st_nk += nk;
         }
-        // one K-tile; PS >= 0: also issue the pending stores of the previous tile, SPP per phase (DEFER)
+        // one K-tile; PS >= 0: also issue pending stores 0..3 of the previous tile, one per phase (DEFER)
         auto ktile = [&](const int t, auto ps_tag) {
             constexpr int PS = decltype(ps_tag)::value;
             // K-tiles t+1 / t+2 of the stream: past the end of this tile they are the next tile's first ones
@@ -215,8 +217,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             READ_A(a_cur, 0)
             if (has1) stage(w1, nrem1, 128, B_RING + b_nxt + HALF);
             if constexpr (PS >= 0) {
-                pend_store(std::integral_constant<int, SPP * 0>{});
-                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 0 + 1>{});
+                pend_store(std::integral_constant<int, 0>{});
+                if constexpr (PQ0 > 1) pend_store(std::integral_constant<int, 1>{});
             }
             S_BARRIER();
             STAMP_IV(0)
@@ -227,8 +229,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             READ_B(b_cur, 2)
             if (has2) stage(a2, mrem2, 0, a_nx2);
             if constexpr (PS >= 0) {
-                pend_store(std::integral_constant<int, SPP * 1>{});
-                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 1 + 1>{});
+                pend_store(std::integral_constant<int, PQ0>{});
+                if constexpr (PQ1 > 1) pend_store(std::integral_constant<int, PQ0 + 1>{});
             }
             S_BARRIER();
             STAMP_IV(2)
@@ -239,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             READ_A(a_cur, 4)
             if (has2) stage(a2, mrem2, 128, a_nx2 + HALF);
             if constexpr (PS >= 0) {
-                pend_store(std::integral_constant<int, SPP * 2>{});
-                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 2 + 1>{});
+                pend_store(std::integral_constant<int, PQ0 + PQ1>{});
+                if constexpr (PQ2 > 1) pend_store(std::integral_constant<int, PQ0 + PQ1 + 1>{});
             }
             S_BARRIER();
             STAMP_IV(4)
@@ -252,9 +254,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             if (has2) {
                 stage(w2, nrem2, 0, B_RING + b_cur);
                 // leave in flight: A(t+2) and B_lo(t+2) (six pieces) -- and the deferred stores issued among them
-                if constexpr (PS >= 0 && SPP == 2) {
+                if constexpr (PS >= 0 && PQ_BEFORE_WAIT == 6) {
                     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                } else if constexpr (PS >= 0 && PQ_BEFORE_WAIT == 5) {
+                    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
                 } else if constexpr (PS >= 0) {
+                    static_assert(PS < 0 || PQ_BEFORE_WAIT == 3, "counted wait");
                     asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 } else {
                     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -264,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             }
             if (st_on) st_wait += __builtin_amdgcn_s_memtime() - st_w0;
             if constexpr (PS >= 0) {
-                pend_store(std::integral_constant<int, SPP * 3>{});
-                if constexpr (SPP > 1) pend_store(std::integral_constant<int, SPP * 3 + 1>{});
+                pend_store(std::integral_constant<int, PQ_BEFORE_WAIT>{});
+                if constexpr (NDEF - PQ_BEFORE_WAIT > 1) pend_store(std::integral_constant<int, PQ_BEFORE_WAIT + 1>{});
             }
             S_BARRIER();
             STAMP_IV(6)
@@ -279,6 +284,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         };
         int t_first = 0;
         if (DEFER && pend_base != nullptr) {  // wave-uniform: the previous tile left its lower half pending
+            // all deferred stores ride in the first K-tile (a second store-carrying instance of the body, or a
+            // register rotation through one instance, spills 30+ VGPRs and loses more than it hides)
             ktile(0, std::integral_constant<int, 0>{});
             t_first = 1;
             pend_base = nullptr;
@@ -466,26 +473,36 @@ hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps
     return hipGetLastError();
 }
 
-hipError_t launch_gemm256(int epilogue, const GemmArgs& g, hipStream_t s);
-
 hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int defer) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     if (g.K <= 0 || (g.K % TK) != 0) return hipErrorInvalidValue;
-    if (g.K < 2 * TK) return launch_gemm256(epilogue, g, s);  // the cross-tile stream looks two K-tiles ahead
+    if (g.K < 2 * TK) return hipErrorInvalidValue;  // the cross-tile stream looks two K-tiles ahead (launch_gemm routes K = 64 to the 128 x 128 kernel)
     if (defer == 8) {
         switch (epilogue) {
             case EPI_BIAS: return launch256r<EPI_BIAS, 8>(g, s);
             case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU, 8>(g, s);
             case EPI_BIAS_RES: return launch256r<EPI_BIAS_RES, 8>(g, s);
+            case EPI_BIAS_RES_STATS: return launch256r<EPI_BIAS_RES_STATS, 8>(g, s);
             case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS, 8>(g, s);
             case EPI_LN_BIAS_GELU: return launch256r<EPI_LN_BIAS_GELU, 8>(g, s);
             default: break;  // the other epilogues have no deferred form
+        }
+    } else if (defer == 6) {
+        switch (epilogue) {
+            case EPI_BIAS: return launch256r<EPI_BIAS, 6>(g, s);
+            case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU, 6>(g, s);
+            case EPI_BIAS_RES: return launch256r<EPI_BIAS_RES, 6>(g, s);
+            case EPI_BIAS_RES_STATS: return launch256r<EPI_BIAS_RES_STATS, 6>(g, s);
+            case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS, 6>(g, s);
+            case EPI_LN_BIAS_GELU: return launch256r<EPI_LN_BIAS_GELU, 6>(g, s);
+            default: break;
         }
     } else if (defer == 4) {
         switch (epilogue) {
             case EPI_BIAS: return launch256r<EPI_BIAS, 4>(g, s);
             case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU, 4>(g, s);
             case EPI_BIAS_RES: return launch256r<EPI_BIAS_RES, 4>(g, s);
+            case EPI_BIAS_RES_STATS: return launch256r<EPI_BIAS_RES_STATS, 4>(g, s);
             case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS, 4>(g, s);
             case EPI_LN_BIAS_GELU: return launch256r<EPI_LN_BIAS_GELU, 4>(g, s);
             default: break;
@@ -495,6 +512,7 @@ hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int d
         case EPI_BIAS: return launch256r<EPI_BIAS>(g, s);
         case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU>(g, s);
         case EPI_BIAS_RES: return launch256r<EPI_BIAS_RES>(g, s);
+        case EPI_BIAS_RES_STATS: return launch256r<EPI_BIAS_RES_STATS>(g, s);
         case EPI_PATCH: return launch256r<EPI_PATCH>(g, s);
         case EPI_F32: return launch256r<EPI_F32>(g, s);
         case EPI_LN_BIAS: return launch256r<EPI_LN_BIAS>(g, s);

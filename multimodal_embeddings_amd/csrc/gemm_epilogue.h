@@ -23,6 +23,28 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);  // v_rcp_f32 (1 ulp); __frcp_rn would expand to a full IEEE division
 }
 
+// ---- LayerNorm statistics in ONE canonical summation order ---------------------------------------------
+// Shared by the EPI_BIAS_RES_STATS epilogue (partial sums while the rounded outputs are still in registers) and
+// by the stand-alone kernels of rowops.hip, so that an embedding does not depend on which of them ran:
+//   per 64-column slice, four column groups g = 0..3 (columns 16 j + 4 g + r, j and r ascending), each summed by
+//   v_dot2c_f32_bf16 over its packed pairs in that order; slice total ((g0 + g1) + (g2 + g3)); row totals over
+//   the slices sequentially in f64; mean = S / d, var = Q / d - mean^2 (>= 0), rstd = 1 / sqrt(var + eps).
+typedef __attribute__((ext_vector_type(2))) __bf16 ln_bf16x2;
+__device__ __forceinline__ void ln_accumulate(uint2 pk, float& s, float& q) {
+    const ln_bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+    const ln_bf16x2 a = __builtin_bit_cast(ln_bf16x2, pk.x), b = __builtin_bit_cast(ln_bf16x2, pk.y);
+    s = __builtin_amdgcn_fdot2_f32_bf16(a, one, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(a, a, q, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(b, one, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(b, b, q, false);
+}
+__device__ __forceinline__ float2 ln_finish_row(double S, double Q, int d, float eps) {
+    const double mean = S / d;
+    double var = Q / d - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    return make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
 struct EpiRow {
     int64_t orow;  // output row (EPI_PATCH remaps patch rows past the [CLS] rows)
     int prow;      // position row for EPI_PATCH
@@ -82,7 +104,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& g, int m, const EpiRow
     }
     if (EPI == EPI_PATCH) v += *(const f32x4*)(g.pos + (int64_t)er.prow * g.N + n);
     bf16_t* o = (bf16_t*)g.out + er.orow * g.ldo + n;
-    if (EPI == EPI_BIAS_RES) {
+    if (EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_STATS) {  // (partial sums of edge tiles: the host re-derives those rows)
         const bf16x4 rv = *(const bf16x4*)((const bf16_t*)g.res + er.orow * g.ldo + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
@@ -138,8 +160,11 @@ __device__ __forceinline__ int row16_col(int jp, int fq) { return ((fq & 1) ? (j
 template <int EPI, int NDEF = 0, class Between>
 __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&acc)[8][4], int mw, int nw, int fr, int fq,
                                                      Between&& between, uint4* pend = nullptr) {
-    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU,
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU ||
+                      EPI == EPI_BIAS_RES_STATS,
                   "epilogue_wave_128x64: unsupported epilogue");
+    constexpr bool RES = EPI == EPI_BIAS_RES || EPI == EPI_BIAS_RES_STATS;
+    constexpr bool STATS = EPI == EPI_BIAS_RES_STATS;
     constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU;
     constexpr bool GELU = EPI == EPI_BIAS_GELU || EPI == EPI_LN_BIAS_GELU;
     // wave-uniform row bases (SGPR pairs) + 32-bit lane offsets: saddr addressing
@@ -158,8 +183,8 @@ __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&
 #pragma unroll
         for (int i = 0; i < 8; ++i) st[i] = *(const float2*)(g.ln_stats + 2 * (int64_t)(mw + i * 16 + fr));
     }
-    uint4 rv[EPI == EPI_BIAS_RES ? 8 : 1][2];
-    if (EPI == EPI_BIAS_RES) {
+    uint4 rv[RES ? 8 : 1][2];
+    if (RES) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             rv[i][0] = *(const uint4*)(resb + (int64_t)i * 16 * g.ldo + lo0);
@@ -169,6 +194,11 @@ __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&
     asm volatile("" ::: "memory");
     between();
     asm volatile("" ::: "memory");
+    float psum[STATS ? 8 : 1], psq[STATS ? 8 : 1];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) psum[i] = psq[i] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -191,13 +221,18 @@ __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&
                     v1[r] = gelu_erf(v1[r]);
                 }
             }
-            if (EPI == EPI_BIAS_RES) {
+            if (RES) {
                 uint2 rp, rq;
                 row16_to_pair(rv[i][jp >> 1], rp, rq);
                 v0 += unpack_bf16x4(rp);
                 v1 += unpack_bf16x4(rq);
             }
-            const uint4 packed = pair_to_row16(pack_bf16x4(v0), pack_bf16x4(v1));
+            const uint2 pk0 = pack_bf16x4(v0), pk1 = pack_bf16x4(v1);
+            if (STATS) {  // canonical order: column tiles j ascending, the two packed pairs of a tile in order
+                ln_accumulate(pk0, psum[i], psq[i]);
+                ln_accumulate(pk1, psum[i], psq[i]);
+            }
+            const uint4 packed = pair_to_row16(pk0, pk1);
             if (NDEF > 0 && i >= 8 - NDEF / 2) {
                 pend[(i - (8 - NDEF / 2)) * 2 + (jp >> 1)] = packed;
             } else {
@@ -205,9 +240,32 @@ __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&
             }
         }
     }
+    if (STATS) {
+        // 16 per-lane partials (8 row blocks x {sum, sum of squares}) over this lane's 16 columns of the wave's
+        // 64-column slice -> totals over the four lanes (fq = 0..3) that share a row, as ((fq0 + fq1) + (fq2 + fq3)).
+        // Two swap levels reduce all 16 at once: v_permlane16_swap leaves the pair sums of quantity a in the even
+        // 16-lane rows and those of b in the odd rows, v_permlane32_swap then pairs the lane halves.
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {  // row block k: rows 0 / 2 of the result pair psum over fq, rows 1 / 3 psq
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(psum[k]), __float_as_uint(psq[k]), false, false);
+            t[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // even rows: psum[k] over (fq, fq + 1); odd rows: psq[k]
+        }
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[2 * k]), __float_as_uint(t[2 * k + 1]), false, false);
+            u[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // lanes 0..31: row block 2k; lanes 32..63: row block 2k + 1
+        }
+        // lane (fq, fr): fq & 1 selects the plane (0 sum, 1 sum of squares), fq >> 1 the row block 2k + (fq >> 1)
+        float* plane = g.ln_part + ((int64_t)(fq & 1) * (g.N >> 6) + (nw >> 6)) * g.ln_part_rows + mw + (fq >> 1) * 16 + fr;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) plane[k * 32] = u[k];
+    }
 }
 
 template <int EPI>
 constexpr bool epi_has_fast_path() {
-    return EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU;
+    return EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES || EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_GELU ||
+           EPI == EPI_BIAS_RES_STATS;
 }

@@ -15,7 +15,10 @@ enum GemmEpilogue {
     //   out = bf16(rstd[m] * (acc - mean[m] * colsum[n]) + bias'[n])             (QKV)
     EPI_LN_BIAS = 5,
     EPI_LN_BIAS_GELU = 6, // same, then erf-GELU                                      (fc1)
-    EPI_TOPK = 7          // no output matrix: every acc[m,n] >= thr[m] is appended to row m's candidate list (K12)
+    EPI_TOPK = 7,         // no output matrix: every acc[m,n] >= thr[m] is appended to row m's candidate list (K12)
+    // EPI_BIAS_RES that also leaves, per output row and 64-column slice, the LayerNorm partial sums (sum x, sum x^2 of
+    // the ROUNDED outputs) in ln_part: the next LayerNorm's statistics then need no pass over the residual stream
+    EPI_BIAS_RES_STATS = 8
 };
 
 struct GemmArgs {
@@ -30,6 +33,8 @@ struct GemmArgs {
     float* outf;
     int64_t ldf;
     const float* ln_stats;  // [M,2] (mean, rstd) per row, for EPI_LN_*
+    float* ln_part;         // EPI_BIAS_RES_STATS: [2][N/64][ln_part_rows] f32 partial (sum, sum of squares) planes
+    int64_t ln_part_rows;
     const float* colsum;    // [N] sum_k W'[n,k], for EPI_LN_*
     // EPI_TOPK: per-row threshold thr[m * thr_stride]; candidates (value, column) of row m go to
     // cand_val / cand_idx [m * cand_cap + k], k = atomic slot from cand_count[m]; a full list raises *overflow
@@ -55,6 +60,13 @@ hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps
 hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, float eps, hipStream_t s);
 // per-row LayerNorm statistics of bf16 rows of 768: stats[row] = (mean, rstd)
 hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats, hipStream_t s);
+// the same statistics in the CANONICAL summation order shared with the EPI_BIAS_RES_STATS epilogue, for rows
+// [row0, row1) of bf16 rows of `d` (d % 64 == 0, d <= 1024): one pass over x
+hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s);
+// finishes rows [0, rows) from the partial planes an EPI_BIAS_RES_STATS GEMM left: part [2][d/64][part_rows]
+hipError_t launch_ln_finish(const float* part, int64_t part_rows, int64_t rows, int d, float eps, float* stats, hipStream_t s);
+// true when launch_gemm(variant) runs the 256 x 256 kernel (whose fast-path epilogue writes the partial planes)
+bool gemm_runs_256(const GemmArgs& g, int variant);
 // x[b*197 + 0, :] = bf16(cls + pos[0])
 hipError_t launch_cls_rows(void* x, const float* cls, const float* pos, int B, hipStream_t s);
 // final LayerNorm on row b*197+tok, L2 normalise, write f32 and/or bf16
@@ -64,6 +76,8 @@ hipError_t launch_pool(const void* x, const float* gamma, const float* beta, int
 hipError_t launch_normalise_rows(const float* x, int64_t rows, int d, void* y, hipStream_t s);
 // fused multi-head attention, T=197, dh=64, 12 heads; qkv [B*197, 2304] -> out [B*197, 768]
 hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s);
+// diagnostic: stamped build, stamps uint64[B][8][8]
+hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s);
 
 struct CropDesc {  // one per crop, built on the host by capi
     int64_t src_off;   // byte offset into pix

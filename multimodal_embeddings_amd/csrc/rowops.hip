@@ -5,6 +5,7 @@
 // in f32 registers, two wave reductions (mean, then centred variance -- the same two-pass
 // form torch's LayerNorm uses, transformers modeling_vit.py:261-262,348), 8-byte stores.
 #include "common.h"
+#include "gemm_epilogue.h"
 #include "kernels.h"
 
 namespace {
@@ -75,6 +76,52 @@ __global__ __launch_bounds__(256) void ln_stats_rows(const bf16_t* __restrict__ 
     }
     const float rstd = rsqrtf(wave_sum(q) * (1.0f / VIT_D) + eps);
     if (lane == 0) *(float2*)(stats + 2 * row) = make_float2(mean, rstd);
+}
+
+// The same statistics in the canonical order of gemm_epilogue.h (ln_accumulate / ln_finish_row): one wave per
+// row, lane = (slice, column group g); 48 of the 64 lanes carry data at d = 768.  Used wherever no
+// EPI_BIAS_RES_STATS epilogue produced the partial sums: the first LayerNorm of a pass, small problems that run
+// the 128 x 128 kernel, the rows of a ragged last row tile.
+__global__ __launch_bounds__(256) void ln_stats_canonical_rows(const bf16_t* __restrict__ x, int64_t row0, int64_t row1, int d, float eps,
+                                                               float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= row1) return;
+    const int slice = lane >> 2, grp = lane & 3, nslice = d >> 6;
+    float s = 0.f, q = 0.f;
+    if (slice < nslice) {
+        const bf16_t* xr = x + row * d + slice * 64 + grp * 4;
+        uint2 pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk[j] = *(const uint2*)(xr + j * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ln_accumulate(pk[j], s, q);
+    }
+    s += __shfl_xor(s, 1, 64);  // g0 + g1 | g2 + g3
+    q += __shfl_xor(q, 1, 64);
+    s += __shfl_xor(s, 2, 64);  // (g0 + g1) + (g2 + g3)
+    q += __shfl_xor(q, 2, 64);
+    double S = 0.0, Q = 0.0;
+    for (int k = 0; k < nslice; ++k) {
+        S += (double)__shfl(s, 4 * k, 64);
+        Q += (double)__shfl(q, 4 * k, 64);
+    }
+    if (lane == 0) *(float2*)(stats + 2 * row) = ln_finish_row(S, Q, d, eps);
+}
+
+// rows [0, rows): the partial planes of an EPI_BIAS_RES_STATS GEMM -> (mean, rstd); one thread per row, the
+// plane reads are coalesced over the rows
+__global__ __launch_bounds__(256) void ln_finish_rows(const float* __restrict__ part, int64_t part_rows, int64_t rows, int d, float eps,
+                                                      float* __restrict__ stats) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const int nslice = d >> 6;
+    double S = 0.0, Q = 0.0;
+    for (int k = 0; k < nslice; ++k) {
+        S += (double)part[(int64_t)k * part_rows + row];
+        Q += (double)part[(int64_t)(nslice + k) * part_rows + row];
+    }
+    *(float2*)(stats + 2 * row) = ln_finish_row(S, Q, d, eps);
 }
 
 __global__ __launch_bounds__(256) void cls_rows(bf16_t* __restrict__ x, const float* __restrict__ cls,
@@ -194,6 +241,20 @@ hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta
 hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     hipLaunchKernelGGL(ln_stats_rows, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, rows, eps, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s) {
+    if (row1 <= row0) return hipSuccess;
+    if (d <= 0 || (d % 64) != 0 || d > 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_stats_canonical_rows, dim3((unsigned)((row1 - row0 + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, row0, row1, d, eps,
+                       stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_ln_finish(const float* part, int64_t part_rows, int64_t rows, int d, float eps, float* stats, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(ln_finish_rows, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, part, part_rows, rows, d, eps, stats);
     return hipGetLastError();
 }
 

@@ -150,6 +150,23 @@ def test_ln_fusion_on_off_agree(engine, golden_dir):
     ea = _check_embeddings(a.cpu().numpy(), want)
     eb = _check_embeddings(b.cpu().numpy(), want)
     assert float((1.0 - (a * b).sum(dim=1)).max()) <= 2e-4, (ea, eb)
+    # folded LayerNorm: statistics from one pass over x (mode 1) and from the partial sums the producing GEMM's
+    # epilogue leaves (mode 2) follow ONE canonical summation order -> bit-identical embeddings, also on a batch
+    # with a ragged last row tile (300 crops = 59 100 rows = 230 tiles of 256 + 220 rows) and for every GEMM variant
+    crops = synthetic_crops(300, seed=9)
+    pixb, offsb, hwb = _pack(list(crops))
+    engine.set_ln_fusion(1)
+    ref, _ = engine.embed(pixb, offsb, hwb)
+    for variant in (0, 1, 3, 4):
+        engine.set_gemm_variant(variant)
+        for mode in (2, 1):
+            engine.set_ln_fusion(mode)
+            got, _ = engine.embed(pixb, offsb, hwb)
+            assert torch.equal(ref, got), (variant, mode)
+    engine.set_gemm_variant(0)
+    engine.set_ln_fusion(2)
+    want300 = _oracle_embed(list(crops[:6]), make_vit_weights(seed=1), "cls")
+    _check_embeddings(ref[:6].cpu().numpy(), want300)
 
 
 def test_embed_hot_weights(engine_hot, golden_dir):

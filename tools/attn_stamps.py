@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Where a head iteration of the attention kernel (K5) spends its cycles, per wave, from the stamped build."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from multimodal_embeddings_amd._lib import Engine
+
+NAMES = ["wait own", "barrier", "issue next", "S^T", "softmax", "P.V", "handover+stores"]
+
+
+def main():
+    eng = Engine(0)
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    ms, st = eng.attention_stamps(B, iters=10)
+    st = st.astype(np.float64)
+    heads = st[:, :, 7]
+    per = st[:, :, :7] / np.maximum(heads[:, :, None], 1)
+    print(f"attention B={B}: {ms:.3f} ms per launch = {ms * 1e3 / (B / 256.0) / 12:.2f} us per head per CU-slot; bytes {B * 197 * 3072 * 2 / ms / 1e9:.2f} TB/s")
+    print("cycles per head (mean over workgroups):   " + "  ".join(f"{n:>15s}" for n in NAMES) + "    total")
+    for w in range(8):
+        m = per[:, w].mean(axis=0)
+        print(f"wave {w}{' (staging)' if w == 7 else '          '}                     " + "  ".join(f"{v:15.0f}" for v in m) + f"  {m.sum():7.0f}")
+
+
+if __name__ == "__main__":
+    main()
