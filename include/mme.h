@@ -255,7 +255,8 @@ int mme_gemm_stamps(mme_ctx* ctx, int M, int N, int K, uint64_t* stamps_host);
  * its stamped build once.  stamps_host uint64[B workgroups][8 waves][8]: s_memtime cycles summed over the 12 head
  * iterations of the wave -- [0] wait for its own requests, [1] workgroup barrier, [2] issue of the next head's
  * requests (K/V LDS-DMA on wave 7, Q prefetch on the others), [3] S^T = K.Q^T, [4] softmax, [5] O^T = V^T.P^T,
- * [6] hand-over + output stores; [7] heads processed. */
+ * [6] hand-over + output stores; [7] heads processed.  Wave 7 (staging only) carries in [5] / [6] the s_memtime cycles and
+ * s_memrealtime ticks (100 MHz) of the whole workgroup: [5] / [6] x 100 MHz = the clock the chip held. */
 int mme_attention_stamps(mme_ctx* ctx, int B, int iters, double* avg_ms, uint64_t* stamps_host);
 
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------

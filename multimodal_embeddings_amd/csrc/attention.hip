@@ -52,7 +52,10 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // PIPE: the softmax rides inside the MFMA loops (default); false = the phase-by-phase form it replaced (A/B).
 template <int NB, bool STAMP = false, bool PIPE = true>
 __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B, int hsplit,
-                                                         unsigned long long* stamps = nullptr) {
+                                                         unsigned long long* stamps = nullptr, int dbg_arg = 0) {
+    // ablation switches of the STAMPED build only (results invalid): 1 no K re-reads, 2 no K/V requests after the
+    // first head, 4 no maximum, 8 no exponentials
+    const int dbg = STAMP ? dbg_arg : 0;
     constexpr int TROWS = AttnGeom<NB>::TROWS, KV_BYTES = AttnGeom<NB>::KV_BYTES, BUF_BYTES = AttnGeom<NB>::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) char lds[];  // NB x (K | V)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,6 +80,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         const char* hb = base + h * ROWB;
         char* kdst = lds + buf * BUF_BYTES;
         if (wave != 7) return;  // the wave without a query block does all the staging
+        if ((dbg & 2) && h != h_begin) return;
         for (int p = 0; p < 2 * NPIECE; ++p) {
             const bool isv = p >= NPIECE;
             const int pp = isv ? p - NPIECE : p;
@@ -84,7 +88,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
             const int slot = lane & 7;
             const int chunk = isv ? (slot ^ (((row >> 1) & 1) << 2)) : (slot ^ ((row >> 1) & 7));
             const char* src = hb + (size_t)min(row, VIT_T - 1) * QKV_LD + (isv ? 2 : 1) * VIT_D * 2 + chunk * 16;
-            glds16(src, kdst + (isv ? KV_BYTES : 0) + pp * 1024);
+            // LDS-DMA through inline asm, so that hipcc does not know these loads write LDS: told through the builtin it
+            // orders every later LDS read behind them with `s_waitcnt vmcnt(0)` -- in the middle of the head iteration,
+            // where that also waits for the Q prefetch and the previous head's stores.  The ordering that is needed
+            // (pieces landed before the NEXT head reads them) is the counted wait + barrier at the top of the loop.
+            const unsigned dst = (unsigned)(size_t)(LDS_AS char*)(kdst + (isv ? KV_BYTES : 0) + pp * 1024);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "v"(src), "s"(__builtin_amdgcn_readfirstlane(dst))
+                         : "memory");
         }
     };
 
@@ -106,6 +119,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
     if (active) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + h_begin * ROWB + ks * 32);
+        // Complete these loads HERE.  Left pending into the loop they make hipcc put `s_waitcnt vmcnt(0)` in front of
+        // the first MFMA of every head iteration (it cannot tell the iterations apart), which also waits for the Q
+        // prefetch of the next head issued a few instructions earlier and for the previous head's output stores:
+        // a full memory latency exposed per head (stamped: ~2 000 of the ~10 000 cycles of a head iteration).
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(qf[ks]));
     }
 
     unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0;
@@ -116,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
         st_prev = now;                                               \
     }
     if (STAMP) st_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_c0 = STAMP ? st_prev : 0, st_r0 = STAMP ? __builtin_amdgcn_s_memrealtime() : 0;
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);  // the later-dispatched half loses VALU arbitration otherwise
     for (int h = h_begin; h < h_end; ++h) {
         const int buf = NB == 3 ? (h - h_begin) % 3 : (h - h_begin) & 1;
@@ -168,38 +188,47 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                 // the softmax rides inside the two MFMA loops of the SAME wave: the running maximum of tile kt - 1
                 // is taken while the four MFMAs of tile kt execute, and the exponentials / bf16 conversion of
                 // P.V step i + 1 are computed between the two MFMAs of step i.
-                bf16x8 kf[2][4];
+                // S^T key tiles in pairs: the two accumulation chains of a pair alternate in the matrix pipe, so no MFMA
+                // waits for its predecessor's result; the K fragments of the next pair are requested first
+                bf16x8 kf[2][2][4];  // [pair parity][tile of the pair][k step]
+                auto read_k = [&](int kt, bf16x8 (&dst)[4]) {
+                    if ((dbg & 1) && kt >= 2) return;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[0][ks] = *(const bf16x8*)(Kl + r * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                    for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8*)(Kl + (kt * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                };
+                read_k(0, kf[0][0]);
+                read_k(1, kf[0][1]);
                 float mx = -INFINITY, mx1 = -INFINITY;
+                auto tile_max = [&](const f32x16& t) {
+                    if (dbg & 4) return;
 #pragma unroll
-                for (int kt = 0; kt < 7; ++kt) {
-                    if (kt + 1 < 7) {
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks)
-                            kf[(kt + 1) & 1][ks] = *(const bf16x8*)(Kl + ((kt + 1) * 32 + r) * ROWB + (((2 * ks + hh) ^ ksw) << 4));
+                    for (int e = 0; e < 16; e += 4) {
+                        mx = fmaxf(fmaxf(mx, t[e]), t[e + 1]);
+                        mx1 = fmaxf(fmaxf(mx1, t[e + 2]), t[e + 3]);
                     }
-                    f32x16 a;
+                };
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+                for (int kp = 0; kp < 4; ++kp) {  // pairs (0,1) (2,3) (4,5) and the single tile 6
+                    const int kt = 2 * kp;
+                    if (kt + 2 < 7) read_k(kt + 2, kf[(kp + 1) & 1][0]);
+                    if (kt + 3 < 7) read_k(kt + 3, kf[(kp + 1) & 1][1]);
+                    f32x16 a, b;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt & 1][ks], qf[ks], a, 0, 0, 0);
+                    for (int e = 0; e < 16; ++e) a[e] = b[e] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kp & 1][0][ks], qf[ks], a, 0, 0, 0);
+                        if (kt + 1 < 7) b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kp & 1][1][ks], qf[ks], b, 0, 0, 0);
+                    }
                     s[kt] = a;
-                    if (kt >= 1) {
-#pragma unroll
-                        for (int e = 0; e < 16; e += 4) {
-                            mx = fmaxf(fmaxf(mx, s[kt - 1][e]), s[kt - 1][e + 1]);
-                            mx1 = fmaxf(fmaxf(mx1, s[kt - 1][e + 2]), s[kt - 1][e + 3]);
-                        }
+                    if (kt + 1 < 7) s[kt + 1] = b;
+                    if (kp >= 1) {  // the previous pair is complete: its maximum rides under this pair's MFMAs
+                        tile_max(s[kt - 2]);
+                        tile_max(s[kt - 1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 ATTN_STAMP(3)  // S^T (+ running maximum)
-#pragma unroll
-                for (int e = 0; e < 16; e += 4) {
-                    mx = fmaxf(fmaxf(mx, s[5][e]), s[5][e + 1]);
-                    mx1 = fmaxf(fmaxf(mx1, s[5][e + 2]), s[5][e + 3]);
-                }
                 mx = fmaxf(mx, mx1);
                 // key of s[kt][e] = 32kt + (e&3) + 8(e>>2) + 4hh ; keys >= 197 are padding: of the last
                 // tile only e = 0..3 can be valid (keys 192..195 in the lower lane half, 196 in the upper)
@@ -216,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                     for (int j = 0; j < 8; ++j) {
                         constexpr int kt = I >> 1;
                         const int e = 8 * (I & 1) + j;
-                        float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][e], sc, nmx));
+                        float pv = (dbg & 8) ? s[kt][e] : __builtin_amdgcn_exp2f(fmaf(s[kt][e], sc, nmx));
                         if (kt == 6 && !(e < 4 && e + 4 * hh < VIT_T - 192)) pv = 0.f;
                         sum4[j & 3] += pv;
                         pf[j] = (bf16_t)pv;
@@ -362,6 +391,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 #pragma unroll
         for (int i = 0; i < 7; ++i) o[i] = st[i];
         o[7] = (unsigned long long)(h_end - h_begin);
+        if (wave == 7) {  // the staging wave has no compute phases: its slots 5 / 6 carry the clock pair of the workgroup
+            o[5] = __builtin_amdgcn_s_memtime() - st_c0;
+            o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        }
     }
 #undef ATTN_STAMP
 }
@@ -400,8 +433,9 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
 
 // diagnostic: the stamped build (two buffers, one workgroup per crop); stamps = uint64[B][8 waves][8], zeroed by the caller
 hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s) {
+    const int dbg = getenv("MME_ATTN_DEBUG") ? atoi(getenv("MME_ATTN_DEBUG")) : 0;
     if (B <= 0) return hipSuccess;
     if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2, true>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
-    hipLaunchKernelGGL((attn_fwd_t197<2, true>), dim3(B), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, 1, stamps);
+    hipLaunchKernelGGL((attn_fwd_t197<2, true>), dim3(B), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, 1, stamps, dbg);
     return hipGetLastError();
 }
