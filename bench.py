@@ -81,8 +81,9 @@ def launch_ranks(n: int, argv) -> int:
 
     Runs before torch is imported: this parent never initialises a GPU, and nothing is exec'ed from a
     process that has (the children are new interpreters).  Rank 0's stdout (the one JSON line) passes
-    through; the other ranks' stdout goes to stderr.  Replaces the reference's in-process device fan-out
-    (deprecated_package/embedder.py:191-224) with one process per GPU."""
+    through -- only its JSON line: a backend that chats on stdout (gloo prints its connection banner there) must not
+    break the one-line contract; the other ranks' stdout goes to stderr.  Replaces the reference's in-process device
+    fan-out (deprecated_package/embedder.py:191-224) with one process per GPU."""
     port = free_port()
     procs = []
     for r in range(n):
@@ -90,9 +91,12 @@ def launch_ranks(n: int, argv) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
     rc = 0
     try:
+        for line in procs[0].stdout:  # ends when rank 0 closes its stdout
+            (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
         for p in procs:
             code = p.wait()
             rc = rc or code

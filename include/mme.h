@@ -32,7 +32,8 @@ enum {
     MME_E_ARG = -1,     /* bad argument (null pointer, size, alignment) */
     MME_E_STATE = -2,   /* call order (e.g. forward before load) */
     MME_E_HIP = -3,     /* HIP runtime / launch failure */
-    MME_E_NOMEM = -4
+    MME_E_NOMEM = -4,
+    MME_E_COMM = -5     /* RCCL missing or a collective failed */
 };
 
 typedef struct mme_ctx mme_ctx;
@@ -259,10 +260,30 @@ int mme_gemm_stamps(mme_ctx* ctx, int M, int N, int K, uint64_t* stamps_host);
  * s_memrealtime ticks (100 MHz) of the whole workgroup: [5] / [6] x 100 MHz = the clock the chip held. */
 int mme_attention_stamps(mme_ctx* ctx, int B, int iters, double* avg_ms, uint64_t* stamps_host);
 
+/* ---- multi-GPU: the ONE exchange step of the path ------------------------------------------
+ * Replaces the hand-back of per-device results through Python lists by the reference's thread pool
+ * (deprecated_package/embedder.py:208-224): every rank embeds its contiguous block of the corpus and the
+ * [rows, d] bf16 shards are all-gathered over RCCL (xGMI) so that each rank can compute its row block of the
+ * cosine matrix / its page pairs / its neighbour lists against all N rows.
+ *   mme_comm_unique_id  rank 0 makes the 128-byte rendezvous id and hands it to the other ranks by any
+ *                       means (a file, MPI, a socket);
+ *   mme_comm_init       every rank, collectively: communicator for this context's GPU;
+ *   mme_allgather       all[r * rows .. (r+1) * rows) = rank r's shard, asynchronous on `stream`;
+ *                       equal shards (pad the last rank's block: rows are independent);
+ *   mme_comm_destroy.
+ * `comm` is an ncclComm_t: a communicator the caller created itself with RCCL works as well.  RCCL is resolved
+ * at run time (the copy PyTorch loaded, else librccl.so.1; MME_RCCL_LIB overrides) -- libmme.so does not link it,
+ * and a missing RCCL only fails these four calls (MME_E_COMM). */
+#define MME_COMM_ID_BYTES 128
+int mme_comm_unique_id(mme_ctx* ctx, uint8_t id_host[MME_COMM_ID_BYTES]);
+int mme_comm_init(mme_ctx* ctx, const uint8_t id_host[MME_COMM_ID_BYTES], int rank, int world, void** comm_out);
+int mme_comm_destroy(mme_ctx* ctx, void* comm);
+int mme_allgather(mme_ctx* ctx, void* comm, const uint16_t* shard_dev, int64_t rows, int d, uint16_t* all_dev, void* stream);
+
 /* ---- timing of the kernels by class (HIP events on the launch stream) ----------------------
  * class ids: 0 preprocess, 1 gemm, 2 layernorm, 3 attention, 4 pool, 5 cosine, 6 page_reduce, 7 cluster,
- * 8 neighbours */
-#define MME_NUM_KERNEL_CLASSES 9
+ * 8 neighbours, 9 all-gather */
+#define MME_NUM_KERNEL_CLASSES 10
 int mme_profile_enable(mme_ctx* ctx, int on);
 int mme_profile_reset(mme_ctx* ctx);
 /* synchronises the recorded events; ms[c] = total ms, launches[c] = launch count per class */

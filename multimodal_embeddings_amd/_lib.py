@@ -14,8 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmme.so")
 
-NUM_KERNEL_CLASSES = 9
-KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "cluster", "neighbours")
+NUM_KERNEL_CLASSES = 10
+KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "cluster", "neighbours", "allgather")
 
 
 class MmeError(RuntimeError):
@@ -67,6 +67,10 @@ EXPORTS = {
     "mme_set_neighbour_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mme_gemm_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mme_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mme_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "mme_comm_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "mme_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_attention_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
@@ -361,6 +365,31 @@ class Engine:
         st = np.zeros((256, 2, 16), dtype=np.uint64)
         self._check(self.lib.mme_gemm_stamps(self.h, M, N, K, st.ctypes.data), "mme_gemm_stamps")
         return st
+
+    # ---- the one collective, without torch.distributed (mme.h: mme_comm_*, mme_allgather) ---------------
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._check(self.lib.mme_comm_unique_id(self.h, buf), "mme_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        comm = C.c_void_p()
+        self._check(self.lib.mme_comm_init(self.h, buf, int(rank), int(world), C.byref(comm)), "mme_comm_init")
+        return comm
+
+    def comm_destroy(self, comm):
+        self._check(self.lib.mme_comm_destroy(self.h, comm), "mme_comm_destroy")
+
+    def allgather(self, comm, shard, world: int, out=None):
+        """shard: bf16 CUDA tensor [rows, d] (same rows on every rank) -> [world * rows, d] on every rank."""
+        t = self.torch
+        assert shard.dtype == t.bfloat16 and shard.is_contiguous()
+        rows, d = shard.shape
+        if out is None:
+            out = t.empty((world * rows, d), dtype=t.bfloat16, device=shard.device)
+        self._check(self.lib.mme_allgather(self.h, comm, shard.data_ptr(), rows, d, out.data_ptr(), self._stream()), "mme_allgather")
+        return out
 
     def attention_stamps(self, B, iters=5):
         """(avg ms of the product kernel, uint64[B, 8, 8] cycle stamps of the stamped build; see mme.h)."""

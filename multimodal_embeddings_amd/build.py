@@ -18,7 +18,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libmme.so")
-SOURCES = ["gemm.hip", "gemm256r.hip", "rowops.hip", "attention.hip", "preprocess.hip", "page_reduce.hip", "cluster.hip", "neighbours.hip", "launch_state.hip", "capi.hip"]
+SOURCES = ["gemm.hip", "gemm256r.hip", "rowops.hip", "attention.hip", "preprocess.hip", "page_reduce.hip", "cluster.hip", "neighbours.hip", "launch_state.hip", "comm.hip", "capi.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "mme.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"])
     return LIB
 
 

@@ -33,7 +33,7 @@ struct LayerDev {
     float *qkv_cs, *qkv_bf, *fc1_cs, *fc1_bf;
 };
 
-enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7, KC_NEIGH = 8 };
+enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7, KC_NEIGH = 8, KC_COMM = 9 };
 
 struct EventPair {
     hipEvent_t a, b;
@@ -1033,6 +1033,52 @@ int mme_gemm_stamps(mme_ctx* c, int M, int N, int K, uint64_t* stamps_host) {
     // ~0.5 s of back-to-back launches of the product kernel first: the clock stamps ([13], [14]) are only
     // meaningful once DVFS has settled under this load
     return gemm_bench_impl(c, M, N, K, EPI_BIAS, 3, 150, &ms, stamps_host);
+}
+
+// ---- the one collective (RCCL over xGMI) -------------------------------------------------------------------
+#define RCCL_TRY(c, expr)                                                                           \
+    do {                                                                                            \
+        const int e_ = (expr);                                                                      \
+        if (e_ != 0) return fail((c), MME_E_COMM, "%s: %s", #expr, rccl_error_string(e_));          \
+    } while (0)
+
+int mme_comm_unique_id(mme_ctx* c, uint8_t id[MME_COMM_ID_BYTES]) {
+    if (!c || !id) return fail(c, MME_E_ARG, "mme_comm_unique_id: null argument");
+    if (const char* why = rccl_ready()) return fail(c, MME_E_COMM, "%s", why);
+    RCCL_TRY(c, rccl_unique_id(id));
+    return MME_OK;
+}
+
+int mme_comm_init(mme_ctx* c, const uint8_t id[MME_COMM_ID_BYTES], int rank, int world, void** comm) {
+    if (!c || !id || !comm) return fail(c, MME_E_ARG, "mme_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(c, MME_E_ARG, "mme_comm_init: rank %d outside 0..%d", rank, world - 1);
+    if (const char* why = rccl_ready()) return fail(c, MME_E_COMM, "%s", why);
+    HIP_TRY(c, hipSetDevice(c->device));
+    *comm = nullptr;
+    RCCL_TRY(c, rccl_comm_init(comm, world, id, rank));
+    return MME_OK;
+}
+
+int mme_comm_destroy(mme_ctx* c, void* comm) {
+    if (!c) return MME_E_ARG;
+    if (!comm) return MME_OK;
+    if (const char* why = rccl_ready()) return fail(c, MME_E_COMM, "%s", why);
+    HIP_TRY(c, hipSetDevice(c->device));
+    RCCL_TRY(c, rccl_comm_destroy(comm));
+    return MME_OK;
+}
+
+int mme_allgather(mme_ctx* c, void* comm, const uint16_t* shard, int64_t rows, int d, uint16_t* all, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (!comm || rows < 0 || d <= 0) return fail(c, MME_E_ARG, "mme_allgather: null communicator or bad sizes (rows=%lld d=%d)", (long long)rows, d);
+    if (rows == 0) return MME_OK;
+    if (!shard || !all) return fail(c, MME_E_ARG, "mme_allgather: null pointer");
+    if (const char* why = rccl_ready()) return fail(c, MME_E_COMM, "%s", why);
+    HIP_TRY(c, hipSetDevice(c->device));
+    Timed t(c, (hipStream_t)stream, KC_COMM);
+    // bf16 rows travel as bytes (bit-exact whatever the RCCL build thinks of bf16 arithmetic)
+    RCCL_TRY(c, rccl_allgather_bytes(shard, all, (size_t)rows * d * 2, comm, (hipStream_t)stream));
+    return MME_OK;
 }
 
 int mme_attention_stamps(mme_ctx* c, int B, int iters, double* avg_ms, uint64_t* stamps_host) {

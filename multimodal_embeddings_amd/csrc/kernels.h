@@ -138,3 +138,11 @@ hipError_t launch_topk_candidates(const float* cand_val, const int32_t* cand_idx
 hipError_t launch_cluster(const double* S, int P, int n_clusters, int mode, char* ws, int32_t* labels_out, int32_t* k_out,
                           double* scores_out, hipStream_t s);
 size_t cluster_workspace_bytes(int P);
+
+// RCCL, resolved at run time (comm.hip)
+const char* rccl_ready();  // nullptr = usable, else why not
+const char* rccl_error_string(int code);
+int rccl_unique_id(void* id128);
+int rccl_comm_init(void** comm, int world, const void* id128, int rank);
+int rccl_comm_destroy(void* comm);
+int rccl_allgather_bytes(const void* send, void* recv, size_t bytes, void* comm, hipStream_t s);

@@ -31,17 +31,51 @@ from .cross_compare import default_engine
 logger = logging.getLogger("multimodal_embeddings_amd")
 
 
+def _where_mask(metadatas, where):
+    """chroma `where` filter -> list[bool].  Supported (all the reference's call sites use the first form):
+    {"key": {"$eq": v}}, {"key": {"$ne": v}}, {"key": v}, {"$and": [...]}, {"$or": [...]}."""
+    n = len(metadatas)
+    if not where:
+        return [True] * n
+    if len(where) != 1:
+        raise ValueError("where: one condition per level; combine conditions with $and / $or")
+    (key, cond), = where.items()
+    if key in ("$and", "$or"):
+        parts = [_where_mask(metadatas, w) for w in cond]
+        return [all(p[i] for p in parts) if key == "$and" else any(p[i] for p in parts) for i in range(n)]
+    if isinstance(cond, dict):
+        (op, val), = cond.items()
+    else:
+        op, val = "$eq", cond
+    if op == "$eq":
+        return [m is not None and key in m and m[key] == val for m in metadatas]
+    if op == "$ne":
+        return [m is not None and m.get(key) != val for m in metadatas]
+    raise ValueError(f"where operator {op!r} is not supported")
+
+
 class RegionCollection:
-    """Minimal in-memory stand-in for the chroma collection (db_operations.py:17-63).
+    """In-memory stand-in for the chroma collection (db_operations.py:17-63) with the calls the hot path makes.
 
     Holds what region_processor.py:141-149 upserts: ids, embeddings, metadatas (with
-    `parent_image_name`, `region_type`, `area_percentage`, `is_region`).  Only the calls
-    the compare stage makes are provided: `upsert`, `get`, `count`.
+    `parent_image_name`, `region_type`, `area_percentage`, `is_region`).  `upsert` / `add`, `get`, `count`
+    and `query` have chroma's argument names and return shapes, so the reference's call sites
+    (wrc:79-84, region_compare.py:165-170, cross_compare.py:119-123, demo_queries.py:61-66) run unchanged
+    against it.  `query` is exact (no HNSW): the ranking is computed on the GPU by kernel K12
+    (`mme_neighbours`) over the L2-normalised bf16 rows -- distance ascending, ties in insertion order.
+    `metric`: "cosine" (d = 1 - cos; the reference's stated intent, db_operations.py:29) or "sqeuclidean"
+    (d = 2 - 2 cos on unit vectors, chroma's default space).
     """
 
-    def __init__(self):
+    def __init__(self, metric="cosine", engine=None):
+        if metric not in ("cosine", "sqeuclidean"):
+            raise ValueError("metric must be 'cosine' or 'sqeuclidean'")
+        self.metric = metric
+        self.engine = engine
+        self.metadata = {"hnsw_space": metric}
         self.ids, self.embeddings, self.metadatas, self.documents = [], [], [], []
         self._pos = {}
+        self._device_rows = None  # unit bf16 rows of all embeddings, rebuilt after an upsert
 
     def upsert(self, ids, embeddings, documents=None, metadatas=None):
         documents = documents or [None] * len(ids)
@@ -56,6 +90,7 @@ class RegionCollection:
                 self.embeddings.append(e)
                 self.documents.append(d)
                 self.metadatas.append(m)
+        self._device_rows = None
 
     add = upsert
 
@@ -65,8 +100,8 @@ class RegionCollection:
     def get(self, ids=None, include=None, where=None):
         rows = range(len(self.ids)) if ids is None else [self._pos[i] for i in ids if i in self._pos]
         if where:
-            (key, cond), = where.items()
-            rows = [r for r in rows if self.metadatas[r] is not None and self.metadatas[r].get(key) == cond["$eq"]]
+            keep = _where_mask(self.metadatas, where)
+            rows = [r for r in rows if keep[r]]
         rows = list(rows)
         return {
             "ids": [self.ids[r] for r in rows],
@@ -74,6 +109,80 @@ class RegionCollection:
             "metadatas": [self.metadatas[r] for r in rows],
             "documents": [self.documents[r] for r in rows],
         }
+
+    def query(self, query_embeddings=None, n_results=10, where=None, include=("metadatas", "documents", "distances"), engine=None):
+        """chroma's `Collection.query`: for every query vector the `n_results` nearest stored vectors that pass
+        `where`, as lists of lists (one inner list per query), distance ascending.
+
+        Exact brute force on the GPU: the candidates that pass `where` and the query vectors are stacked into one
+        table of unit bf16 rows; kernel K12 ranks the query rows against it with the queries' own group masked out
+        (so a query never returns itself or another query).  Up to 128 results per query come from K12's streaming
+        selection; larger requests sort a K9 cosine block."""
+        from .cross_compare import to_unit_bf16
+
+        if query_embeddings is None or len(query_embeddings) == 0:
+            raise ValueError("query_embeddings is required (text queries need the language tower, which is out of scope)")
+        keep = _where_mask(self.metadatas, where)
+        rows = [r for r in range(len(self.ids)) if keep[r] and self.embeddings[r] is not None and len(self.embeddings[r]) > 0]
+        nq, n_c = len(query_embeddings), len(rows)
+        k = max(0, min(int(n_results), n_c))
+        out = {"ids": [[] for _ in range(nq)], "distances": None, "metadatas": None, "documents": None, "embeddings": None}
+        for key in ("distances", "metadatas", "documents", "embeddings"):
+            if key in include:
+                out[key] = [[] for _ in range(nq)]
+        if k == 0:
+            return out
+        engine = engine or self.engine or default_engine()
+        t = engine.torch
+        if self._device_rows is None:
+            have = [r for r in range(len(self.ids)) if self.embeddings[r] is not None and len(self.embeddings[r]) > 0]
+            self._device_rows = (have, to_unit_bf16([self.embeddings[r] for r in have], engine))
+        have, table = self._device_rows
+        if len(rows) != len(have):
+            where_of = {r: i for i, r in enumerate(have)}
+            sel = t.tensor([where_of[r] for r in rows], dtype=t.long, device=table.device)
+            cand = table.index_select(0, sel)
+        else:
+            cand = table
+        q = to_unit_bf16(query_embeddings, engine)
+        if k <= 128:
+            stacked = t.cat([cand, q], dim=0)
+            group = t.zeros(n_c + nq, dtype=t.int32, device=stacked.device)
+            group[n_c:] = 1
+            idx, sim = engine.neighbours(stacked, group, row0=n_c, nrows=nq, fetch=k, top_n=k)
+        else:
+            block = engine.cosine(q, cand)
+            order = t.sort(block, dim=1, descending=True, stable=True)
+            idx, sim = order.indices[:, :k], order.values[:, :k]
+        idx, sim = idx.cpu().numpy(), sim.cpu().numpy().astype(np.float64)
+        dist = 1.0 - sim if self.metric == "cosine" else 2.0 - 2.0 * sim
+        for qi in range(nq):
+            picks = [rows[c] for c in idx[qi] if c >= 0]
+            out["ids"][qi] = [self.ids[r] for r in picks]
+            if out["distances"] is not None:
+                out["distances"][qi] = [float(d) for d in dist[qi][: len(picks)]]
+            if out["metadatas"] is not None:
+                out["metadatas"][qi] = [self.metadatas[r] for r in picks]
+            if out["documents"] is not None:
+                out["documents"][qi] = [self.documents[r] for r in picks]
+            if out["embeddings"] is not None:
+                out["embeddings"][qi] = [self.embeddings[r] for r in picks]
+        return out
+
+
+def safe_query(collection, query_embedding, n_results, where_clause, max_retries=3):
+    """wrc:73-95: the retry ladder guards an hnswlib failure mode ("Cannot return the results in a contigious 2D
+    array") that an exact ranking does not have; kept so call sites port unchanged."""
+    for attempt in range(max_retries):
+        try:
+            return collection.query(query_embeddings=[query_embedding], n_results=n_results,
+                                    include=["metadatas", "documents", "distances"], where=where_clause)
+        except RuntimeError as e:
+            if "Cannot return the results in a contigious 2D array" in str(e) and attempt < max_retries - 1:
+                n_results = max(1, int(n_results * 0.8))
+                continue
+            raise
+    return None
 
 
 def same_prefix_skip(image_names, prefix_length=config.PREFIX_LENGTH):

@@ -24,6 +24,7 @@ Fixtures written
   vit_cases.npz          transformers.ViTModel (seeded synthetic weights) hidden states / embeddings
   crops/*.png            a few bundled region crops (data) incl. the 16 crops of config C1
   crops_expected.npz     Pillow resize + MllamaImageProcessorPil outputs for those crops
+  query_cases.json       a brute-force store queried through the REAL safe_query (wrc:73-95): ids / distances
 """
 from __future__ import annotations
 
@@ -289,6 +290,36 @@ def golden_neighbours():
     print("image neighbour golden:", int((iidx >= 0).sum()), "picks over", len(names), "images")
 
 
+def golden_query(w):
+    """`collection.query` results as the reference's own helper obtains them: the REAL `safe_query` (wrc:73-95) driving a
+    brute-force store with the three `where` shapes of the call sites (wrc:204-208 parent page, region_compare.py:165-170
+    is_region, cross_compare.py:119-123 none) -> query_cases.json (inputs + expected ids / distances)."""
+    rng = np.random.default_rng(53)
+    pages = [f"Paper {p:02d}.png" for p in range(6)]
+    ids, metas, docs = [], [], []
+    for k in range(180):
+        p = int(rng.integers(0, 6))
+        region = k % 9 != 0
+        ids.append(f"{'region' if region else 'image'}_{k}")
+        metas.append({"parent_image_name": pages[p], "is_region": region, "region_type": ["plain_text", "title", "figure"][k % 3],
+                      "area_percentage": float(rng.uniform(0.1, 20.0))})
+        docs.append(f"doc {k}")
+    emb = unit_vectors(len(ids), 64, 59, clusters=5)
+    emb[11] = emb[12] = emb[100]  # exact ties: insertion order decides
+    store = StoreFake(ids, emb, metas, docs)
+    queries = unit_vectors(7, 64, 61, clusters=5)
+    queries[3] = emb[100]  # a stored vector as the query: distance 0 to its copies
+    cases = []
+    for qi, (where, n) in enumerate([({"parent_image_name": {"$eq": pages[2]}}, 10), ({"is_region": {"$eq": True}}, 30), (None, 25),
+                                     ({"is_region": {"$eq": True}}, 15), ({"parent_image_name": {"$eq": pages[5]}}, 100),
+                                     ({"parent_image_name": {"$eq": "absent.png"}}, 10), (None, 150)]):
+        res = w.safe_query(store, queries[qi].tolist(), n, where)
+        cases.append({"query": qi, "where": where, "n_results": n, "ids": res["ids"][0], "distances": res["distances"][0]})
+    json.dump({"ids": ids, "metadatas": metas, "documents": docs, "embeddings": emb.tolist(), "queries": queries.tolist(), "cases": cases},
+              open(os.path.join(HERE, "query_cases.json"), "w"))
+    print("query golden:", [len(c["ids"]) for c in cases], "results")
+
+
 def golden_regions():
     """RegionProcessor.process_image_regions (region_processor.py:62) + the real
     DocLayoutDetector.get_region_image (doclayout_detector.py:165) on a seeded page -> region_rows.json:
@@ -377,6 +408,10 @@ def main():
     os.chdir(scratch)
     os.makedirs("output", exist_ok=True)
     w, ref_embedder = import_reference()
+    if "--only-query" in sys.argv:
+        golden_query(w)
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
     if "--only-next" in sys.argv:  # the SURVEY 8(f) rows only (leaves the other fixtures untouched)
         golden_neighbours()
         golden_regions()
@@ -514,6 +549,7 @@ def main():
     golden_neighbours()
     golden_regions()
     golden_tiles()
+    golden_query(w)
 
     # ---- 5. last_pooling -------------------------------------------------------------
     g = torch.Generator().manual_seed(3)

@@ -217,3 +217,65 @@ def test_fused_form_refuses_problems_it_cannot_take(engine):
     finally:
         engine.set_neighbour_mode("auto")
     assert engine.neighbours(e16, None)[0].shape == (3000, 10)
+
+
+def test_collection_query_matches_the_reference_helper(engine, golden_dir):
+    """`RegionCollection.query` through the mirror of the reference's `safe_query`: chroma's
+    lists-of-lists shape, `where` filters of the three call sites, distance ascending, ties in insertion order.
+    Expected: (a) what the REAL safe_query obtained from a brute-force f64 store on the same data
+    (tests/golden/query_cases.json) -- same ids up to the near-ties bf16 rows move, distances to bf16 precision;
+    (b) decision for decision, a f64 ranking of the SAME unit bf16 rows the kernel ranks (ids exact, distances to f32)."""
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection, safe_query
+
+    g = json.load(open(os.path.join(golden_dir, "query_cases.json")))
+    col = RegionCollection(engine=engine)
+    col.upsert(ids=g["ids"], embeddings=g["embeddings"], documents=g["documents"], metadatas=g["metadatas"])
+    emb = np.asarray(g["embeddings"], dtype=np.float32)
+    rows16 = engine.normalise_rows(torch.from_numpy(emb).cuda()).float().cpu().numpy().astype(np.float64)
+    same = total = 0
+    for case in g["cases"]:
+        q = g["queries"][case["query"]]
+        res = safe_query(col, q, case["n_results"], case["where"])
+        assert set(res) >= {"ids", "distances", "metadatas", "documents"} and len(res["ids"]) == 1
+        ids, dist = res["ids"][0], res["distances"][0]
+        assert len(ids) == len(case["ids"]) == len(dist) == len(res["metadatas"][0]) == len(res["documents"][0])
+        if not ids:
+            continue
+        assert dist == sorted(dist)
+        pos = {i: k for k, i in enumerate(g["ids"])}
+        assert res["metadatas"][0] == [g["metadatas"][pos[i]] for i in ids] and res["documents"][0] == [g["documents"][pos[i]] for i in ids]
+        # (a) the reference helper's own result on the f64 store
+        total += len(ids)
+        same += len(set(ids) & set(case["ids"]))
+        want_d = dict(zip(case["ids"], case["distances"]))
+        assert all(abs(d - want_d[i]) <= 1e-2 for i, d in zip(ids, dist) if i in want_d)
+        # (b) f64 ranking of the kernel's operands
+        q16 = engine.normalise_rows(torch.tensor([q], dtype=torch.float32).cuda()).float().cpu().numpy().astype(np.float64)[0]
+        if case["where"]:
+            (key, cond), = case["where"].items()
+            cand = [r for r, m in enumerate(g["metadatas"]) if m.get(key) == cond["$eq"]]
+        else:
+            cand = list(range(len(g["ids"])))
+        d64 = 1.0 - rows16[cand] @ q16
+        d32 = (1.0 - (rows16[cand] @ q16).astype(np.float32).astype(np.float64))
+        order = np.argsort(d64, kind="stable")[: case["n_results"]]
+        ref_ids = [g["ids"][cand[k]] for k in order]
+        if ids != ref_ids:  # only values closer than the f32 accumulation error may swap
+            for a, b in zip(ids, ref_ids):
+                if a != b:
+                    assert abs(d64[cand.index(pos[a])] - d64[cand.index(pos[b])]) <= 4e-6
+        assert np.abs(np.array(dist) - np.array([d32[cand.index(pos[i])] for i in ids])).max() <= 4e-6
+    assert same / total > 0.93, same / total
+    # the stored vector used as query 3 sits at rows 11, 12 and 100: distance ~0, insertion order
+    res = col.query(query_embeddings=[g["queries"][3]], n_results=3)
+    assert res["ids"][0] == [g["ids"][11], g["ids"][12], g["ids"][100]] and max(res["distances"][0]) <= 1e-2
+    # several queries at once, squared-L2 space (chroma's default, SURVEY G1), include subset
+    col2 = RegionCollection(metric="sqeuclidean", engine=engine)
+    col2.upsert(ids=g["ids"], embeddings=g["embeddings"], metadatas=g["metadatas"])
+    many = col2.query(query_embeddings=g["queries"][:4], n_results=5, include=["distances"])
+    one = [col.query(query_embeddings=[qv], n_results=5) for qv in g["queries"][:4]]
+    assert many["ids"] == [o["ids"][0] for o in one] and many["metadatas"] is None
+    assert np.allclose(many["distances"], 2.0 * np.array([o["distances"][0] for o in one]), atol=1e-6)
+    # an upsert invalidates the device copy of the table
+    col.upsert(ids=["new"], embeddings=[g["queries"][0]], metadatas=[{"is_region": True}])
+    assert col.query(query_embeddings=[g["queries"][0]], n_results=1)["ids"] == [["new"]]

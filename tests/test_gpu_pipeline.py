@@ -364,3 +364,31 @@ def test_one_ranks_share_of_c4_end_to_end(embedder):
     assert float((own - own.T).abs().max()) == 0.0
     assert float((torch.diagonal(own) - 1.0).abs().max()) <= 1e-2
     assert float(sim.abs().max()) <= 1.0 + 1e-2
+
+
+def test_allgather_through_the_c_abi_world_1(embedder):
+    """mme_comm_unique_id / mme_comm_init / mme_allgather / mme_comm_destroy (SURVEY 8b's export list): RCCL resolved
+    at run time, a one-rank communicator on this GPU, the shard arrives bit for bit, the call is timed as class 9.
+    (Several ranks need several GPUs: the N-rank path is exercised by the driver's multi-GPU bench.)"""
+    eng = embedder.engine
+    uid = eng.comm_unique_id()
+    assert isinstance(uid, bytes) and len(uid) == 128 and any(uid)
+    comm = eng.comm_init(uid, rank=0, world=1)
+    try:
+        g = torch.Generator(device=embedder.device).manual_seed(3)
+        shard = eng.normalise_rows(torch.randn(8192, 768, generator=g, device=embedder.device))
+        eng.profile(True)
+        out = eng.allgather(comm, shard, world=1)
+        table = torch.zeros((8192 + 16, 768), dtype=torch.bfloat16, device=embedder.device)
+        eng.allgather(comm, shard, world=1, out=table[:8192])
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        assert torch.equal(out, shard) and torch.equal(table[:8192], shard) and not table[8192:].any()
+        assert prof["allgather"][1] == 2
+    finally:
+        eng.comm_destroy(comm)
+    from multimodal_embeddings_amd._lib import MmeError
+
+    with pytest.raises(MmeError):
+        eng.comm_init(uid, rank=3, world=2)

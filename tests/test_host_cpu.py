@@ -309,14 +309,17 @@ def test_bench_starts_its_own_ranks(tmp_path):
 
     probe = tmp_path / "probe.py"
     probe.write_text("import os, sys\nprint('rank', os.environ['RANK'], os.environ['LOCAL_RANK'], os.environ['WORLD_SIZE'], "
-                     "os.environ['MASTER_ADDR'], 'torch' in sys.modules, sys.argv[1:], flush=True)\nsys.exit(3 if os.environ['RANK'] == '1' and '--fail' in sys.argv else 0)\n")
+                     "os.environ['MASTER_ADDR'], 'torch' in sys.modules, sys.argv[1:], flush=True)\n"
+                     "print('{\"json\": ' + os.environ['RANK'] + '}', flush=True)\n"
+                     "sys.exit(3 if os.environ['RANK'] == '1' and '--fail' in sys.argv else 0)\n")
     code = ("import sys; sys.path.insert(0, %r); import bench; bench.__file__ = %r; "
             "assert 'torch' not in sys.modules; sys.exit(bench.launch_ranks(2, sys.argv[1:]))" % (ROOT, str(probe)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, "-c", code, "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert "rank 0 0 2 127.0.0.1 False ['--steps', '1']" in r.stdout  # rank 0's stdout is relayed ...
-    assert "rank 1 1 2 127.0.0.1 False ['--steps', '1']" in r.stderr  # ... the other ranks' goes to stderr
+    assert r.stdout.strip() == '{"json": 0}'  # only rank 0's JSON line reaches stdout ...
+    assert "rank 0 0 2 127.0.0.1 False ['--steps', '1']" in r.stderr  # ... its chatter ...
+    assert "rank 1 1 2 127.0.0.1 False ['--steps', '1']" in r.stderr and '{"json": 1}' in r.stderr  # ... and the other ranks go to stderr
     r = subprocess.run([sys.executable, "-c", code, "--fail"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3  # a failing rank fails the launch
     a = bench.parse_args(["--gpus", "8"])
@@ -414,3 +417,27 @@ def test_convert_to_rgb_composites_over_white_like_the_mllama_processor():
     assert differs >= 2  # the transparent inputs really exercise the compositing
     rgb = Image.fromarray(rng.integers(0, 256, (8, 9, 3), dtype=np.uint8), "RGB")
     assert convert_to_rgb(rgb) is rgb
+
+
+def test_collection_where_filters_and_query_shape_without_gpu():
+    """chroma-shaped `where` handling of RegionCollection (the filter of every reference call site is {"key": {"$eq": v}})."""
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection, _where_mask
+
+    metas = [{"p": "a", "is_region": True}, {"p": "b", "is_region": False}, None, {"p": "a"}]
+    assert _where_mask(metas, None) == [True] * 4
+    assert _where_mask(metas, {"p": {"$eq": "a"}}) == [True, False, False, True]
+    assert _where_mask(metas, {"p": "b"}) == [False, True, False, False]
+    assert _where_mask(metas, {"is_region": {"$ne": True}}) == [False, True, False, True]
+    assert _where_mask(metas, {"$and": [{"p": {"$eq": "a"}}, {"is_region": {"$eq": True}}]}) == [True, False, False, False]
+    assert _where_mask(metas, {"$or": [{"p": {"$eq": "b"}}, {"is_region": {"$eq": True}}]}) == [True, True, False, False]
+    with pytest.raises(ValueError):
+        _where_mask(metas, {"p": {"$gt": 1}})
+    col = RegionCollection()
+    col.upsert(ids=["x", "y"], embeddings=[[1.0] * 64, [0.5] * 64], metadatas=[{"p": "a"}, {"p": "b"}])
+    assert col.get(where={"p": {"$eq": "b"}})["ids"] == ["y"] and col.count() == 2
+    empty = col.query(query_embeddings=[[1.0] * 64], n_results=5, where={"p": {"$eq": "zzz"}})  # nothing to rank: no GPU touched
+    assert empty["ids"] == [[]] and empty["distances"] == [[]] and empty["metadatas"] == [[]]
+    with pytest.raises(ValueError):
+        col.query(n_results=3)
+    with pytest.raises(ValueError):
+        RegionCollection(metric="manhattan")

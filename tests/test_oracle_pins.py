@@ -187,6 +187,46 @@ def test_bundled_crop_sizes_equal_int_bbox(golden_dir):
     assert checked == 1862
 
 
+def _pin_crops(files):
+    """worker: oracle.preprocess_crop vs transformers' Mllama processor (live) on a slice of the bundled crops"""
+    from PIL import Image
+    from threadpoolctl import threadpool_limits
+    from transformers.models.mllama.image_processing_pil_mllama import MllamaImageProcessorPil
+
+    threadpool_limits(1)  # one BLAS thread per worker: the pool is the parallelism
+    proc = MllamaImageProcessorPil(size={"height": 224, "width": 224}, max_image_tiles=1, image_mean=list(opre.CLIP_MEAN),
+                                   image_std=list(opre.CLIP_STD))
+    bad = []
+    for f in files:
+        im = Image.open(f)
+        want = proc(images=[im], return_tensors="np")["pixel_values"][0, 0, 0]
+        a = np.array(im.convert("RGB"))
+        nh, nw = opre.fit_to_canvas(*a.shape[:2])
+        if not (np.array_equal(opre.preprocess_crop(a), want)
+                and np.array_equal(opre.pil_bilinear_resize_u8(a, nh, nw), np.array(im.convert("RGB").resize((nw, nh), resample=Image.BILINEAR)))):
+            bad.append(os.path.basename(f))
+    return len(files), bad
+
+
+@pytest.mark.reference
+def test_oracle_preprocessing_is_bit_exact_on_every_bundled_crop():
+    """north_star: "on the bundled newspaper_images set".  All 1862 crops under the reference's output/region_images
+    (178 MB, cannot travel) through oracle.preprocess_crop / pil_bilinear_resize_u8 against live Pillow and live
+    transformers MllamaImageProcessorPil: bit-exact f32 pixel values and bit-exact resized bytes, every crop.
+    (The GPU-side K1 check uses the 24 committed crops plus the bundled size distribution; this pins the checker.)"""
+    import multiprocessing as mp
+
+    crop_dir = "/root/reference/deprecated_package/output/region_images"
+    files = sorted(os.path.join(crop_dir, f) for f in os.listdir(crop_dir) if f.endswith(".png"))
+    assert len(files) == 1862
+    workers = 6
+    parts = [files[k::workers] for k in range(workers)]
+    with mp.get_context("fork").Pool(workers) as pool:
+        results = pool.map(_pin_crops, parts)
+    assert sum(n for n, _ in results) == 1862
+    assert [b for _, bad in results for b in bad] == []
+
+
 def test_neighbour_lists_match_reference_region_report(golden_dir):
     """oracle.neighbour_lists == what create_region_cross_comparison (region_compare.py:25) picked on a
     brute-force store: ranks, same-page / self drops, the literal distance >= 0.3 window (G2)."""
