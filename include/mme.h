@@ -260,6 +260,60 @@ int mme_gemm_stamps(mme_ctx* ctx, int M, int N, int K, uint64_t* stamps_host);
  * s_memrealtime ticks (100 MHz) of the whole workgroup: [5] / [6] x 100 MHz = the clock the chip held. */
 int mme_attention_stamps(mme_ctx* ctx, int B, int iters, double* avg_ms, uint64_t* stamps_host);
 
+/* ---- tile-ViT encoder option: the reference encoder's own vision-tower geometry -------------------
+ * Replaces the vision side of `MllamaForConditionalGeneration.from_pretrained(...)` / `model(**inputs)`
+ * (deprecated_package/embedder.py:75-79,117-126): transformers `MllamaVisionModel` at the checkpoint's configuration
+ * (config.py:58; configuration_mllama.py:61-82 at image_size 560) -- <= 4 tiles of 560 x 560, patch 14, 1 + 1600 tokens
+ * per tile padded to 1608, ONE sequence of 6432 tokens per image, 1280-d, 16 heads of 80, MLP 5120, `layers` local +
+ * `global_layers` tanh-gated layers (32 + 8), the states after `intermediate[]` local layers (3, 7, 15, 23, 30)
+ * concatenated behind the final state -> 1280 * (1 + n_intermediate) = 7680 features per token.  Geometry is fixed
+ * at compile time; the layer counts are free (tests run shallow stacks against the CPU oracle).
+ * Host f32 tensors in the Hugging Face state-dict layout: Linear weights [out, in]; patch_w [1280, 3*14*14] in
+ * (c, ky, kx) order; pos_emb [1601, 1280]; tile_pos_emb [9, 4*1601*1280]; pre_emb / post_emb [9, 4*1280].
+ * Values are rounded to bf16 on upload; the tanh gates are folded into the tables / weights they scale. */
+typedef struct {
+    const float *ln1_g, *ln1_b;           /* input_layernorm */
+    const float *q_w, *k_w, *v_w, *o_w;   /* no biases */
+    const float *ln2_g, *ln2_b;           /* post_attention_layernorm */
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+    float gate_attn, gate_ffn;            /* raw parameters; tanh is applied by the library */
+    int32_t gated;                        /* 1 for the global stack */
+} mme_tile_layer;
+
+typedef struct {
+    int32_t image_size;  /* 560 */
+    int32_t patch_size;  /* 14 */
+    int32_t hidden;      /* 1280 */
+    int32_t heads;       /* 16 */
+    int32_t mlp;         /* 5120 */
+    int32_t max_tiles;   /* 4 */
+    int32_t aspect_ratios; /* 9 = max_aspect_ratio_id + 1 */
+    int32_t layers, global_layers;
+    int32_t n_intermediate;
+    int32_t intermediate[8];
+    float norm_eps;      /* 1e-5 (the encoder layers; layernorm_pre / _post use torch's default 1e-5 too) */
+    float pos_gate, pre_gate, post_gate;
+    const float* class_embedding;
+    const float* patch_w;
+    const float* pos_emb;
+    const float* tile_pos_emb;
+    const float* pre_emb;
+    const float* post_emb;
+    const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+    const mme_tile_layer* layer; /* [layers + global_layers], local stack first */
+} mme_tile_vit_weights;
+
+int mme_load_tile_vit(mme_ctx* ctx, const mme_tile_vit_weights* w);
+
+/* pixel_values_dev f32 [n, 4, 3, 560, 560] (what mme_preprocess_tiles writes), aspect_ids_host / num_tiles_host int32[n]
+ * (its other two outputs).  Any of the three outputs may be NULL:
+ *   hidden_dev    f32 [n, 4, 1601, F]   `last_hidden_state` of the vision model (padding tiles included, as the model returns them)
+ *   emb_f32_dev   f32 [n, F], emb_bf16_dev bf16 [n, F]   the class token of tile 0, L2-normalised: the crop's vector for
+ *                 the compare stage (last_pooling's rule -- one token row, F.normalize -- embedder.py:17-34).
+ * F = 1280 * (1 + n_intermediate).  Images are processed mme_set_chunk (<= 64) at a time. */
+int mme_tile_vit_forward(mme_ctx* ctx, const float* pixel_values_dev, const int32_t* aspect_ids_host, const int32_t* num_tiles_host, int n,
+                         float* hidden_dev, float* emb_f32_dev, uint16_t* emb_bf16_dev, void* stream);
+
 /* ---- multi-GPU: the ONE exchange step of the path ------------------------------------------
  * Replaces the hand-back of per-device results through Python lists by the reference's thread pool
  * (deprecated_package/embedder.py:208-224): every rank embeds its contiguous block of the corpus and the

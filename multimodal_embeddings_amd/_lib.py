@@ -39,6 +39,24 @@ class _Weights(C.Structure):
     ]
 
 
+class _TileLayer(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("ln1_g", "ln1_b", "q_w", "k_w", "v_w", "o_w", "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")] + [
+        ("gate_attn", C.c_float), ("gate_ffn", C.c_float), ("gated", C.c_int32)]
+
+
+class _TileWeights(C.Structure):
+    _fields_ = [
+        ("image_size", C.c_int32), ("patch_size", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32),
+        ("max_tiles", C.c_int32), ("aspect_ratios", C.c_int32), ("layers", C.c_int32), ("global_layers", C.c_int32),
+        ("n_intermediate", C.c_int32), ("intermediate", C.c_int32 * 8), ("norm_eps", C.c_float),
+        ("pos_gate", C.c_float), ("pre_gate", C.c_float), ("post_gate", C.c_float),
+        ("class_embedding", C.POINTER(C.c_float)), ("patch_w", C.POINTER(C.c_float)), ("pos_emb", C.POINTER(C.c_float)),
+        ("tile_pos_emb", C.POINTER(C.c_float)), ("pre_emb", C.POINTER(C.c_float)), ("post_emb", C.POINTER(C.c_float)),
+        ("ln_pre_g", C.POINTER(C.c_float)), ("ln_pre_b", C.POINTER(C.c_float)), ("ln_post_g", C.POINTER(C.c_float)), ("ln_post_b", C.POINTER(C.c_float)),
+        ("layer", C.POINTER(_TileLayer)),
+    ]
+
+
 EXPORTS = {
     "mme_abi_version": (C.c_int, []),
     "mme_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -67,6 +85,8 @@ EXPORTS = {
     "mme_set_neighbour_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "mme_gemm_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "mme_load_tile_vit": (C.c_int, [C.c_void_p, C.POINTER(_TileWeights)]),
+    "mme_tile_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_comm_unique_id": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mme_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "mme_comm_destroy": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -176,6 +196,68 @@ class Engine:
         W.layer = layers
         self._check(self.lib.mme_load_vit(self.h, C.byref(W)), "mme_load_vit")
         self._keep.clear()
+
+    def load_tile_vit(self, w: dict, geom=None):
+        """Hugging Face `MllamaVisionModel` state dict (f32 arrays) -> the tile-ViT encoder of this context."""
+        from .weights import TILE_VIT
+
+        geom = geom or TILE_VIT
+        keep = []
+
+        def arr(name):
+            a = np.ascontiguousarray(w[name], dtype=np.float32)
+            keep.append(a)
+            return _fp(a)
+
+        L = geom.num_layers + geom.num_global_layers
+        layers = (_TileLayer * L)()
+        for i in range(L):
+            gated = i >= geom.num_layers
+            p = f"global_transformer.layers.{i - geom.num_layers}." if gated else f"transformer.layers.{i}."
+            X = layers[i]
+            X.ln1_g, X.ln1_b = arr(p + "input_layernorm.weight"), arr(p + "input_layernorm.bias")
+            X.q_w, X.k_w, X.v_w, X.o_w = (arr(p + f"self_attn.{n}_proj.weight") for n in "qkvo")
+            X.ln2_g, X.ln2_b = arr(p + "post_attention_layernorm.weight"), arr(p + "post_attention_layernorm.bias")
+            X.fc1_w, X.fc1_b, X.fc2_w, X.fc2_b = arr(p + "mlp.fc1.weight"), arr(p + "mlp.fc1.bias"), arr(p + "mlp.fc2.weight"), arr(p + "mlp.fc2.bias")
+            X.gated = int(gated)
+            X.gate_attn = float(w[p + "gate_attn"][0]) if gated else 0.0
+            X.gate_ffn = float(w[p + "gate_ffn"][0]) if gated else 0.0
+        W = _TileWeights()
+        W.image_size, W.patch_size, W.hidden, W.heads, W.mlp = geom.image_size, geom.patch_size, geom.hidden_size, geom.num_heads, geom.intermediate_size
+        W.max_tiles, W.aspect_ratios, W.layers, W.global_layers = geom.max_num_tiles, geom.max_aspect_ratio_id + 1, geom.num_layers, geom.num_global_layers
+        W.n_intermediate = len(geom.intermediate_layers)
+        for k, v in enumerate(geom.intermediate_layers):
+            W.intermediate[k] = int(v)
+        W.norm_eps = float(geom.norm_eps)
+        W.pos_gate = float(w["gated_positional_embedding.gate"][0])
+        W.pre_gate = float(w["pre_tile_positional_embedding.gate"][0])
+        W.post_gate = float(w["post_tile_positional_embedding.gate"][0])
+        W.class_embedding, W.patch_w = arr("class_embedding"), arr("patch_embedding.weight")
+        W.pos_emb, W.tile_pos_emb = arr("gated_positional_embedding.embedding"), arr("gated_positional_embedding.tile_embedding.weight")
+        W.pre_emb, W.post_emb = arr("pre_tile_positional_embedding.embedding.weight"), arr("post_tile_positional_embedding.embedding.weight")
+        W.ln_pre_g, W.ln_pre_b = arr("layernorm_pre.weight"), arr("layernorm_pre.bias")
+        W.ln_post_g, W.ln_post_b = arr("layernorm_post.weight"), arr("layernorm_post.bias")
+        W.layer = layers
+        self._check(self.lib.mme_load_tile_vit(self.h, C.byref(W)), "mme_load_tile_vit")
+        self.tile_features = geom.output_dim
+
+    def tile_vit_forward(self, pixel_values, aspect_ratio_ids, num_tiles, want_hidden=False, want_f32=True, want_bf16=True):
+        """pixel_values f32 CUDA [n, 4, 3, 560, 560] (+ ids / tile counts, as `preprocess_tiles` returns them) ->
+        (hidden f32 [n, 4, 1601, F] | None, emb f32 [n, F] | None, emb bf16 [n, F] | None)."""
+        t = self.torch
+        pv = pixel_values.contiguous()
+        n, F = pv.shape[0], self.tile_features
+        if pv.dtype != t.float32 or tuple(pv.shape[1:]) != (4, 3, 560, 560):
+            raise MmeError("tile_vit_forward: pixel_values must be f32 [n, 4, 3, 560, 560]")
+        ids = np.ascontiguousarray(np.asarray(aspect_ratio_ids).reshape(-1), dtype=np.int32)
+        nt = np.ascontiguousarray(np.asarray(num_tiles).reshape(-1), dtype=np.int32)
+        hidden = t.empty((n, 4, 1601, F), dtype=t.float32, device=pv.device) if want_hidden else None
+        e32 = t.empty((n, F), dtype=t.float32, device=pv.device) if want_f32 else None
+        e16 = t.empty((n, F), dtype=t.bfloat16, device=pv.device) if want_bf16 else None
+        self._check(self.lib.mme_tile_vit_forward(self.h, pv.data_ptr(), ids.ctypes.data, nt.ctypes.data, n,
+                                                  hidden.data_ptr() if want_hidden else None, e32.data_ptr() if want_f32 else None,
+                                                  e16.data_ptr() if want_bf16 else None, self._stream()), "mme_tile_vit_forward")
+        return hidden, e32, e16
 
     def set_normalisation(self, mean, std):
         m = (C.c_float * 3)(*mean)

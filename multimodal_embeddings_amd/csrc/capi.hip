@@ -12,64 +12,14 @@
 #include <string>
 #include <vector>
 
-#include "common.h"
-#include "kernels.h"
+#include "ctx.h"
 
 namespace {
 
 thread_local std::string g_create_error;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
-struct LayerDev {
-    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
-    bf16_t *qkv_w, *o_w, *fc1_w, *fc2_w;
-    float *qkv_b, *o_b, *fc1_b, *fc2_b;
-    // LayerNorm folded into the consuming GEMM: W' = bf16(W * gamma), colsum = sum_k W', b' = b + W . beta
-    bf16_t *qkv_wf, *fc1_wf;
-    float *qkv_cs, *qkv_bf, *fc1_cs, *fc1_bf;
-};
-
-enum KClass { KC_PRE = 0, KC_GEMM = 1, KC_LN = 2, KC_ATTN = 3, KC_POOL = 4, KC_COS = 5, KC_PAGE = 6, KC_CLUSTER = 7, KC_NEIGH = 8, KC_COMM = 9 };
-
-struct EventPair {
-    hipEvent_t a, b;
-    int cls;
-};
-
 }  // namespace
 
-struct mme_ctx {
-    int device = 0;
-    std::string err;
-    bool loaded = false;
-    float ln_eps = 1e-12f;
-    int chunk = 4096;
-    int gemm_variant = 0;
-    int ln_mode = 2;  // 0 LayerNorm kernel, 1 folded into the GEMMs + one statistics pass over x, 2 folded + partial sums from the producing epilogue
-    int neigh_mode = 0;  // K12: 0 by size, 1 cosine block through the workspace, 2 fused candidate lists
-    // weights
-    std::vector<void*> allocs;
-    float *cls = nullptr, *pos = nullptr, *patch_b = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
-    bf16_t* patch_w = nullptr;
-    LayerDev layer[VIT_L];
-    float* lut = nullptr;  // [3,256]
-    // workspace (sized for `chunk` crops)
-    int ws_chunk = 0;
-    DevBuf x, hbuf, qkv, att, mlp, stats, lnpart, patches, tmp, crops, hwork, page_ws, cluster_ws, neigh_ws;
-    // host staging for crop tables
-    std::vector<CropDesc> h_crops;
-    std::vector<HWork> h_work;
-    // profiling
-    bool prof = false;
-    std::vector<EventPair> events;
-    size_t events_used = 0;
-};
-
-namespace {
 
 int fail(mme_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -84,11 +34,6 @@ int fail(mme_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(c, expr)                                                                            \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess) return fail((c), MME_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 int ensure(mme_ctx* c, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes) return MME_OK;
@@ -123,13 +68,13 @@ int upload_f32(mme_ctx* c, const float* src, size_t n, float** dst) {
 }
 
 // concatenates up to three [rows_i, cols] f32 matrices row-wise, converts to bf16, uploads
-int upload_bf16(mme_ctx* c, const float* const* srcs, const size_t* rows, int nsrc, size_t cols, bf16_t** dst) {
+int upload_bf16(mme_ctx* c, const float* const* srcs, const size_t* rows, int nsrc, size_t cols, bf16_t** dst, float scale) {
     size_t total = 0;
     for (int i = 0; i < nsrc; ++i) total += rows[i] * cols;
     std::vector<uint16_t> h(total);
     size_t o = 0;
     for (int i = 0; i < nsrc; ++i)
-        for (size_t k = 0; k < rows[i] * cols; ++k) h[o++] = f32_to_bf16_rne(srcs[i][k]);
+        for (size_t k = 0; k < rows[i] * cols; ++k) h[o++] = f32_to_bf16_rne(scale == 1.0f ? srcs[i][k] : srcs[i][k] * scale);
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, total * 2);
     if (e != hipSuccess) return fail(c, MME_E_NOMEM, "hipMalloc weights: %s", hipGetErrorString(e));
@@ -163,7 +108,7 @@ int upload_folded(mme_ctx* c, const float* const* ws, const float* const* bs, co
                 t += (double)w * (double)beta[k];
             }
             hcs[o] = (float)s;
-            hbf[o] = (float)((double)bs[i][n] + t);
+            hbf[o] = (float)((bs[i] ? (double)bs[i][n] : 0.0) + t);
         }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, hw.size() * 2);
@@ -197,25 +142,23 @@ int ensure_workspace(mme_ctx* c) {
     return MME_OK;
 }
 
-struct Timed {
-    mme_ctx* c;
-    hipStream_t s;
-    EventPair* ev = nullptr;
-    Timed(mme_ctx* c_, hipStream_t s_, int cls) : c(c_), s(s_) {
-        if (!c->prof) return;
-        if (c->events_used == c->events.size()) {
-            EventPair p{};
-            if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
-            c->events.push_back(p);
-        }
-        ev = &c->events[c->events_used++];
-        ev->cls = cls;
-        (void)hipEventRecord(ev->a, s);
+Timed::Timed(mme_ctx* c_, hipStream_t s_, int cls) : c(c_), s(s_) {
+    if (!c->prof) return;
+    if (c->events_used == c->events.size()) {
+        EventPair p{};
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+        c->events.push_back(p);
     }
-    ~Timed() {
-        if (ev) (void)hipEventRecord(ev->b, s);
-    }
-};
+    ev = &c->events[c->events_used++];
+    ev->cls = cls;
+    (void)hipEventRecord(ev->a, s);
+}
+Timed::~Timed() {
+    if (ev) (void)hipEventRecord(ev->b, s);
+}
+
+namespace {
+
 
 int set_lut(mme_ctx* c, const float mean[3], const float stdv[3]) {
     // u8 -> ((f32)(f64(u) * (1/255)) - mean) / std : transformers image_transforms.py:89-125, :384-440
@@ -450,6 +393,7 @@ void mme_destroy(mme_ctx* c) {
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
+    tile_vit_free(c);
     for (auto& ev : c->events) {
         (void)hipEventDestroy(ev.a);
         (void)hipEventDestroy(ev.b);

@@ -61,7 +61,7 @@ hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta
 // per-row LayerNorm statistics of bf16 rows of 768: stats[row] = (mean, rstd)
 hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats, hipStream_t s);
 // the same statistics in the CANONICAL summation order shared with the EPI_BIAS_RES_STATS epilogue, for rows
-// [row0, row1) of bf16 rows of `d` (d % 64 == 0, d <= 1024): one pass over x
+// [row0, row1) of bf16 rows of `d` (d % 64 == 0, d <= 2048): one pass over x
 hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s);
 // finishes rows [0, rows) from the partial planes an EPI_BIAS_RES_STATS GEMM left: part [2][d/64][part_rows]
 hipError_t launch_ln_finish(const float* part, int64_t part_rows, int64_t rows, int d, float eps, float* stats, hipStream_t s);
@@ -146,3 +146,13 @@ int rccl_unique_id(void* id128);
 int rccl_comm_init(void** comm, int world, const void* id128, int rank);
 int rccl_comm_destroy(void* comm);
 int rccl_allgather_bytes(const void* send, void* recv, size_t bytes, void* comm, hipStream_t s);
+
+// ---- tile-ViT encoder (tilevit.hip, attention_tiles.hip): Mllama vision tower geometry, fixed at compile time:
+// 4 tiles x (1601 -> 1608) tokens, 1280-d, 16 heads of 80, patch 14 on 560 x 560 tiles
+hipError_t launch_tile_patchify(const float* pv, void* patches, int64_t npatch, hipStream_t s);
+hipError_t launch_tile_assemble(const void* pemb, const float* cls, const float* pre, const float* pos, const float* tilepos, const float* g,
+                                const float* b, const int32_t* aid, void* x, int64_t rows, float eps, hipStream_t s);
+hipError_t launch_tile_ln_post(void* x, const float* g, const float* b, const float* post, const int32_t* aid, int64_t rows, float eps, hipStream_t s);
+hipError_t launch_tile_output(const void* x, const void* inter, int ni, int64_t inter_stride, float* hidden, int64_t out_rows, hipStream_t s);
+hipError_t launch_tile_pool(const void* x, const void* inter, int ni, int64_t inter_stride, int n, float* emb_f32, void* emb_bf16, hipStream_t s);
+hipError_t launch_attention_tiles(const void* qkv, void* out, const int32_t* ntiles_dev, int n, hipStream_t s);

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ln_stats_rows(const bf16_t* __restrict__ 
 }
 
 // The same statistics in the canonical order of gemm_epilogue.h (ln_accumulate / ln_finish_row): one wave per
-// row, lane = (slice, column group g); 48 of the 64 lanes carry data at d = 768.  Used wherever no
+// row, lane = (slice, column group g) for up to two rounds of 16 slices; 48 of the 64 lanes carry data at d = 768.  Used wherever no
 // EPI_BIAS_RES_STATS epilogue produced the partial sums: the first LayerNorm of a pass, small problems that run
 // the 128 x 128 kernel, the rows of a ragged last row tile.
 __global__ __launch_bounds__(256) void ln_stats_canonical_rows(const bf16_t* __restrict__ x, int64_t row0, int64_t row1, int d, float eps,
@@ -87,24 +87,28 @@ __global__ __launch_bounds__(256) void ln_stats_canonical_rows(const bf16_t* __r
     const int lane = threadIdx.x & 63;
     const int64_t row = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= row1) return;
-    const int slice = lane >> 2, grp = lane & 3, nslice = d >> 6;
-    float s = 0.f, q = 0.f;
-    if (slice < nslice) {
-        const bf16_t* xr = x + row * d + slice * 64 + grp * 4;
-        uint2 pk[4];
+    const int slice = lane >> 2, grp = lane & 3, nslice = d >> 6;  // a lane serves slices `slice` and `slice + 16` (d <= 2048)
+    float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk[j] = *(const uint2*)(xr + j * 16);
+    for (int h = 0; h < 2; ++h) {
+        const int sl = slice + 16 * h;
+        if (sl < nslice) {
+            const bf16_t* xr = x + row * d + sl * 64 + grp * 4;
+            uint2 pk[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ln_accumulate(pk[j], s, q);
+            for (int j = 0; j < 4; ++j) pk[j] = *(const uint2*)(xr + j * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ln_accumulate(pk[j], s[h], q[h]);
+        }
+        s[h] += __shfl_xor(s[h], 1, 64);  // g0 + g1 | g2 + g3
+        q[h] += __shfl_xor(q[h], 1, 64);
+        s[h] += __shfl_xor(s[h], 2, 64);  // (g0 + g1) + (g2 + g3)
+        q[h] += __shfl_xor(q[h], 2, 64);
     }
-    s += __shfl_xor(s, 1, 64);  // g0 + g1 | g2 + g3
-    q += __shfl_xor(q, 1, 64);
-    s += __shfl_xor(s, 2, 64);  // (g0 + g1) + (g2 + g3)
-    q += __shfl_xor(q, 2, 64);
     double S = 0.0, Q = 0.0;
     for (int k = 0; k < nslice; ++k) {
-        S += (double)__shfl(s, 4 * k, 64);
-        Q += (double)__shfl(q, 4 * k, 64);
+        S += (double)__shfl(k < 16 ? s[0] : s[1], 4 * (k & 15), 64);
+        Q += (double)__shfl(k < 16 ? q[0] : q[1], 4 * (k & 15), 64);
     }
     if (lane == 0) *(float2*)(stats + 2 * row) = ln_finish_row(S, Q, d, eps);
 }
@@ -246,7 +250,7 @@ hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats,
 
 hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s) {
     if (row1 <= row0) return hipSuccess;
-    if (d <= 0 || (d % 64) != 0 || d > 1024) return hipErrorInvalidValue;
+    if (d <= 0 || (d % 64) != 0 || d > 2048) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ln_stats_canonical_rows, dim3((unsigned)((row1 - row0 + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, row0, row1, d, eps,
                        stats);
     return hipGetLastError();

@@ -194,3 +194,137 @@ def synthetic_crops(n: int, seed: int = 0, size: int = 224, start: int = 0) -> n
         w = counter_u64(seed, 0x7000 + ((start + k) >> 16), words, (start + k) & 0xFFFF)
         out[k] = w.view(np.uint8)
     return out.reshape(n, size, size, 3)
+
+
+# ---- the reference's own vision-tower geometry --------------------------------------------------
+@dataclass(frozen=True)
+class TileViTGeometry:
+    """Mllama vision tower as the reference's checkpoint configures it (`config.py:58`, transformers
+    `configuration_mllama.py:61-82` at image_size 560): <= 4 tiles of 560 x 560, patch 14, 1 + 1600 tokens per tile
+    (padded to 1608), 1280-d, 16 heads of 80, MLP 5120, 32 local + 8 gated global layers, the outputs of five
+    intermediate layers concatenated to the final one -> 7680-d."""
+
+    image_size: int = 560
+    patch_size: int = 14
+    num_channels: int = 3
+    hidden_size: int = 1280
+    num_heads: int = 16
+    intermediate_size: int = 5120
+    num_layers: int = 32
+    num_global_layers: int = 8
+    max_num_tiles: int = 4
+    max_aspect_ratio_id: int = 8
+    intermediate_layers: tuple = (3, 7, 15, 23, 30)
+    norm_eps: float = 1e-5
+
+    @property
+    def num_patches(self) -> int:  # tokens of a tile, class token included
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+    @property
+    def padded_patches(self) -> int:
+        return (self.num_patches + 7) // 8 * 8
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden_size // self.num_heads
+
+    @property
+    def patch_dim(self) -> int:
+        return self.num_channels * self.patch_size * self.patch_size
+
+    @property
+    def output_dim(self) -> int:
+        return self.hidden_size * (1 + len(self.intermediate_layers))
+
+
+TILE_VIT = TileViTGeometry()
+
+
+def tile_vit_tensor_specs(geom: TileViTGeometry = TILE_VIT):
+    """(name, shape, kind, scale) in a fixed order, Hugging Face `MllamaVisionModel` state-dict names."""
+    D, F, P, T = geom.hidden_size, geom.intermediate_size, geom.patch_size, geom.max_num_tiles
+    A = geom.max_aspect_ratio_id + 1
+    emb = D ** -0.5
+    specs = [
+        ("class_embedding", (D,), "matrix", emb),
+        ("patch_embedding.weight", (D, geom.num_channels, P, P), "matrix", 0.02),
+        ("gated_positional_embedding.gate", (1,), "gate", 0.6),
+        ("gated_positional_embedding.embedding", (geom.num_patches, D), "matrix", emb),
+        ("gated_positional_embedding.tile_embedding.weight", (A, T * geom.num_patches * D), "matrix", 0.02),
+        ("pre_tile_positional_embedding.gate", (1,), "gate", 0.4),
+        ("pre_tile_positional_embedding.embedding.weight", (A, T * D), "matrix", 0.02),
+        ("post_tile_positional_embedding.gate", (1,), "gate", -0.5),
+        ("post_tile_positional_embedding.embedding.weight", (A, T * D), "matrix", 0.02),
+        ("layernorm_pre.weight", (D,), "gamma", 0.02),
+        ("layernorm_pre.bias", (D,), "bias", 0.02),
+        ("layernorm_post.weight", (D,), "gamma", 0.02),
+        ("layernorm_post.bias", (D,), "bias", 0.02),
+    ]
+    for stack, count, gated in (("transformer", geom.num_layers, False), ("global_transformer", geom.num_global_layers, True)):
+        for i in range(count):
+            p = f"{stack}.layers.{i}."
+            if gated:
+                specs += [(p + "gate_attn", (1,), "gate", 0.7853981633974483), (p + "gate_ffn", (1,), "gate", 0.7853981633974483)]
+            specs += [
+                (p + "self_attn.q_proj.weight", (D, D), "matrix", 0.02),
+                (p + "self_attn.k_proj.weight", (D, D), "matrix", 0.02),
+                (p + "self_attn.v_proj.weight", (D, D), "matrix", 0.02),
+                (p + "self_attn.o_proj.weight", (D, D), "matrix", 0.02),
+                (p + "mlp.fc1.weight", (F, D), "matrix", 0.02),
+                (p + "mlp.fc1.bias", (F,), "bias", 0.02),
+                (p + "mlp.fc2.weight", (D, F), "matrix", 0.02),
+                (p + "mlp.fc2.bias", (D,), "bias", 0.02),
+                (p + "input_layernorm.weight", (D,), "gamma", 0.02),
+                (p + "input_layernorm.bias", (D,), "bias", 0.02),
+                (p + "post_attention_layernorm.weight", (D,), "gamma", 0.02),
+                (p + "post_attention_layernorm.bias", (D,), "bias", 0.02),
+            ]
+    return specs
+
+
+def hashed_normal4(seed: int, stream: int, n: int, start: int = 0) -> np.ndarray:
+    """Approximate N(0,1) f32 samples for element counters start .. start+n: the four 16-bit lanes of ONE splitmix64 word
+    summed (Irwin-Hall, 4 terms), centred and scaled to unit variance.  Integer provenance like `irwin_hall_normal`,
+    a third of its cost -- the vision tower has 860 M parameters to fill."""
+    i = np.arange(start, start + n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        base = np.uint64(seed & 0xFFFF) * np.uint64(1 << 48) + np.uint64(stream & 0xFFFFFFFF) * np.uint64(1 << 16)
+        w = _splitmix64(_splitmix64(np.uint64(base)) ^ (i * np.uint64(0x2545F4914F6CDD1D)))
+    total = (w & np.uint64(0xFFFF)).astype(np.int32)
+    for lane in (1, 2, 3):
+        total += ((w >> np.uint64(16 * lane)) & np.uint64(0xFFFF)).astype(np.int32)
+    # four U{0..65535}: mean 131070, variance 4 * (65536^2 - 1) / 12 -> sigma = 37837.2247...
+    return (total - 131070).astype(np.float32) * np.float32(1.0 / 37837.224732)
+
+
+def make_tile_vit_weights(seed: int = 2, geom: TileViTGeometry = TILE_VIT, threads: int = 8) -> dict[str, np.ndarray]:
+    """Seeded synthetic weights of the Mllama vision tower, f32 arrays holding bf16-representable values (the reference
+    runs the tower in bf16, embedder.py:78).  A counter-based generator: identical tensors in the build container (where
+    they are loaded into transformers' `MllamaVisionModel` to make the golden vectors) and on the GPU box.  Gates (the
+    tanh-gated embeddings and the gated global layers) get fixed non-zero values so that every gated path carries data;
+    matrices N(0, scale), LayerNorm gamma 1 + N(0, 0.02), biases N(0, 0.02)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    out: dict[str, np.ndarray] = {}
+    jobs = []
+    step = 1 << 22  # elements per block: bounds the uint64 temporaries and gives the thread pool even work
+    for tid, (name, shape, kind, scale) in enumerate(tile_vit_tensor_specs(geom)):
+        n = int(np.prod(shape))
+        if kind == "gate":
+            out[name] = round_to_bf16(np.full(n, scale, dtype=np.float32)).reshape(shape)
+            continue
+        buf = np.empty(n, dtype=np.float32)
+        out[name] = buf.reshape(shape)
+        jobs += [(buf, tid, o, min(step, n - o), scale, kind) for o in range(0, n, step)]
+
+    def fill(job):
+        buf, tid, o, m, scale, kind = job
+        z = hashed_normal4(seed, tid, m, start=o) * np.float32(scale)
+        if kind == "gamma":
+            z += np.float32(1.0)
+        buf[o : o + m] = round_to_bf16(z)
+
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        list(ex.map(fill, jobs))
+    return out

@@ -24,6 +24,8 @@ Fixtures written
   vit_cases.npz          transformers.ViTModel (seeded synthetic weights) hidden states / embeddings
   crops/*.png            a few bundled region crops (data) incl. the 16 crops of config C1
   crops_expected.npz     Pillow resize + MllamaImageProcessorPil outputs for those crops
+  tile_vit_cases.npz     transformers MllamaVisionModel (560 / 14 / 1280-d / 32 + 8 layers, seeded weights) rows per tile grid
+                         (run separately: `make_golden.py --only-tile-vit`, ~15 min of CPU)
   query_cases.json       a brute-force store queried through the REAL safe_query (wrc:73-95): ids / distances
 """
 from __future__ import annotations
@@ -403,11 +405,76 @@ def golden_tiles():
     print("tile golden:", len(cases), "crops; arrangements", sorted({c["aspect_ratio_id"] for c in cases}))
 
 
+def golden_tile_vit():
+    """transformers `MllamaVisionModel(MllamaVisionConfig(image_size=560))` -- the reference encoder's own vision tower
+    (embedder.py:75-79,117-126; 32 local + 8 gated global layers, 1280-d, <= 4 tiles of 1601 tokens, 7680-d output) --
+    holding the seeded synthetic weights of `make_tile_vit_weights(2)`, fp32 on the CPU, on one image per tile
+    arrangement (the first case of every aspect-ratio id in tile_cases.json, through transformers' own image
+    processor) -> tile_vit_cases.npz: per case the rows of tokens {0, 1, 800, 1600} of every real tile (f16) and the
+    oracle restatement's agreement with them."""
+    import time
+
+    import torch
+    from PIL import Image
+    from transformers.models.mllama.configuration_mllama import MllamaVisionConfig
+    from transformers.models.mllama.image_processing_pil_mllama import MllamaImageProcessorPil
+    from transformers.models.mllama.modeling_mllama import MllamaVisionModel
+
+    from multimodal_embeddings_amd.weights import make_tile_vit_weights
+    from oracle import mllama_vision as om
+    from oracle.preprocess import CLIP_MEAN, CLIP_STD
+
+    torch.set_num_threads(8)
+    w = make_tile_vit_weights(2)
+    model = MllamaVisionModel(MllamaVisionConfig(image_size=560)).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    proc = MllamaImageProcessorPil(size={"height": 560, "width": 560}, max_image_tiles=4, image_mean=list(CLIP_MEAN), image_std=list(CLIP_STD))
+    g = json.load(open(os.path.join(HERE, "tile_cases.json")))
+    first = {}
+    for c in g["cases"]:
+        if c["source"].startswith("seed:"):
+            first.setdefault(c["aspect_ratio_id"], c)
+    tokens = [0, 1, 800, 1600]
+    out = {"tokens": np.array(tokens)}
+    sources = []
+    for aid in sorted(first):
+        c = first[aid]
+        seed, hw = c["source"].split(":")[1:]
+        h, wd = map(int, hw.split("x"))
+        img = np.random.default_rng(int(seed)).integers(0, 256, (h, wd, 3), dtype=np.uint8)
+        inp = proc(images=[img], return_tensors="pt")
+        assert int(inp["aspect_ratio_ids"][0, 0]) == aid
+        t0 = time.time()
+        with torch.no_grad():
+            hs = model(pixel_values=inp["pixel_values"], aspect_ratio_ids=inp["aspect_ratio_ids"],
+                       aspect_ratio_mask=inp["aspect_ratio_mask"]).last_hidden_state[0, 0].numpy()
+        nt = c["num_tiles"]
+        rows = hs[:nt][:, tokens]  # [nt, 4, 7680]
+        out[f"rows_{aid}"] = rows.astype(np.float16)
+        sources.append(c["source"])
+        print(f"tile-ViT golden: aspect id {aid} ({nt} tiles, {c['source']}) in {time.time() - t0:.0f} s, |rows| {np.abs(rows).max():.3f}", flush=True)
+        if aid in (1, 6):  # the oracle restatement against the real class: one single-tile and one four-tile image
+            t0 = time.time()
+            got = om.vision_forward(inp["pixel_values"][0, 0].numpy(), aid, nt, w)
+            err = float(np.abs(got[:nt] - hs[:nt]).max() / np.abs(hs[:nt]).max())
+            cos = (got[:nt] * hs[:nt]).sum(-1) / np.linalg.norm(got[:nt], axis=-1) / np.linalg.norm(hs[:nt], axis=-1)
+            print(f"  oracle vs transformers: max rel err {err:.2e}, min token cosine {cos.min():.8f} ({time.time() - t0:.0f} s)", flush=True)
+            assert err < 1e-4 and cos.min() > 1 - 1e-6
+            out[f"oracle_max_rel_err_{aid}"] = np.array(err)
+    out["sources"] = np.array(sources)
+    np.savez_compressed(os.path.join(HERE, "tile_vit_cases.npz"), **out)
+    print("tile-ViT golden written:", sorted(first))
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix="golden_")
     os.chdir(scratch)
     os.makedirs("output", exist_ok=True)
     w, ref_embedder = import_reference()
+    if "--only-tile-vit" in sys.argv:
+        golden_tile_vit()
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
     if "--only-query" in sys.argv:
         golden_query(w)
         shutil.rmtree(scratch, ignore_errors=True)

@@ -1,0 +1,108 @@
+"""Tile-ViT encoder option: the Mllama vision tower geometry of the reference's checkpoint on the GPU
+(mme_load_tile_vit / mme_tile_vit_forward) against the CPU oracle (oracle/mllama_vision.py, itself pinned to
+transformers' MllamaVisionModel) and against rows recorded from that class itself (tests/golden/tile_vit_cases.npz)."""
+import json
+import os
+from dataclasses import replace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from multimodal_embeddings_amd.weights import TILE_VIT, make_tile_vit_weights  # noqa: E402
+
+
+def _image(source):
+    seed, hw = source.split(":")[1:]
+    h, w = map(int, hw.split("x"))
+    return np.random.default_rng(int(seed)).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def _token_cos(a, b):
+    a, b = a.astype(np.float64), b.astype(np.float64)
+    return (a * b).sum(-1) / np.linalg.norm(a, axis=-1) / np.linalg.norm(b, axis=-1)
+
+
+def _prep(engine, arrays):
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+
+    emb = RegionEmbedder(engine=engine)
+    pix, offs, hw = emb.pack(arrays)
+    return engine.preprocess_tiles(pix, offs, hw, 560, 4)
+
+
+def test_shallow_tower_matches_the_oracle_on_padded_and_full_images():
+    """2 local + 2 gated global layers, intermediate states after local layers 0 and 1: every kernel of the option
+    (patchify, assembly with gated embeddings, LayerNorm-folded GEMMs with d = 1280 statistics, flash attention over
+    6432 tokens with the (padding, padding) mask, layernorm_post, gated branches, output gather, pooling) against the
+    fp32 CPU oracle on a 1-tile, a 2-tile and a 4-tile image.  Tolerance: 1e-3 cosine per token (north_star)."""
+    from multimodal_embeddings_amd._lib import Engine
+    from oracle import mllama_vision as om
+
+    geom = replace(TILE_VIT, num_layers=2, num_global_layers=2, intermediate_layers=(0, 1))
+    w = make_tile_vit_weights(3, geom)
+    eng = Engine(0)
+    eng.load_tile_vit(w, geom)
+    rng = np.random.default_rng(4)
+    arrays = [rng.integers(0, 256, s, dtype=np.uint8) for s in [(300, 200, 3), (400, 900, 3), (1000, 1100, 3)]]
+    pv, ids, mask, nt = _prep(eng, arrays)
+    assert nt == [1, 2, 4]
+    for mode in (2, 1):  # LayerNorm statistics from the producing GEMM's partial sums / from a pass over x: same bits
+        eng.set_ln_fusion(mode)
+        hidden, e32, e16 = eng.tile_vit_forward(pv, ids, nt, want_hidden=True)
+        torch.cuda.synchronize()
+        if mode == 2:
+            first = hidden.clone()
+        else:
+            assert torch.equal(first, hidden)
+    host = hidden.cpu().numpy()
+    assert host.shape == (3, 4, 1601, geom.output_dim) and np.isfinite(host).all()
+    pvh = pv.cpu().numpy()
+    for k in range(3):
+        want = om.vision_forward(pvh[k], int(ids[k]), nt[k], w, geom)
+        cos = _token_cos(host[k, : nt[k]], want[: nt[k]])
+        assert cos.min() >= 1 - 1e-3, (k, float(cos.min()))
+        # the padding tiles come out of the model too (they are keys and values of every layer): same bar
+        if nt[k] < 4:
+            assert _token_cos(host[k, nt[k] :], want[nt[k] :]).min() >= 1 - 1e-3
+        pooled = om.pooled_embedding(want)
+        assert 1.0 - float(np.dot(e32[k].cpu().numpy().astype(np.float64), pooled)) <= 1e-3
+        assert abs(float(np.linalg.norm(e32[k].cpu().numpy())) - 1.0) <= 1e-5
+    assert torch.equal(e16.float(), e32.to(torch.bfloat16).float())
+    eng.close()
+
+
+def test_full_tower_matches_rows_recorded_from_transformers(golden_dir):
+    """The full 32 + 8 layer tower with the seeded weights of make_tile_vit_weights(2) on one image per tile
+    arrangement (all eight aspect-ratio ids): rows of tokens {0, 1, 800, 1600} of every real tile against what
+    transformers' MllamaVisionModel(MllamaVisionConfig(image_size=560)) produced for the same pixels (fp32, CPU; recorded
+    by tests/golden/make_golden.py --only-tile-vit).  1e-3 cosine per token, bf16 arithmetic through 40 layers."""
+    from multimodal_embeddings_amd._lib import Engine
+
+    path = os.path.join(golden_dir, "tile_vit_cases.npz")
+    g = np.load(path)
+    sources = [str(s) for s in g["sources"]]
+    tokens = g["tokens"].tolist()
+    cases = json.load(open(os.path.join(golden_dir, "tile_cases.json")))["cases"]
+    by_source = {c["source"]: c for c in cases}
+    eng = Engine(0)
+    eng.load_tile_vit(make_tile_vit_weights(2))
+    eng.set_chunk(4)
+    arrays = [_image(s) for s in sources]
+    pv, ids, mask, nt = _prep(eng, arrays)
+    assert [int(i) for i in ids] == [by_source[s]["aspect_ratio_id"] for s in sources] == list(range(1, 9))
+    hidden, e32, _ = eng.tile_vit_forward(pv, ids, nt, want_hidden=True)  # two passes of four images
+    torch.cuda.synchronize()
+    worst = 1.0
+    for k, s in enumerate(sources):
+        want = g[f"rows_{by_source[s]['aspect_ratio_id']}"].astype(np.float32)  # [tiles, 4, 7680]
+        got = hidden[k, : nt[k]][:, tokens].cpu().numpy()
+        cos = _token_cos(got, want)
+        worst = min(worst, float(cos.min()))
+        assert cos.min() >= 1 - 1e-3, (s, float(cos.min()))
+        cls = want[0, 0].astype(np.float64)
+        assert 1.0 - float(np.dot(e32[k].cpu().numpy().astype(np.float64), cls / np.linalg.norm(cls))) <= 1e-3
+    print("tile-ViT full tower: worst token cosine", worst)
+    eng.close()
