@@ -93,9 +93,11 @@ class RegionEmbedder:
     """Drop-in for `MmE5MllamaEmbedder` on one MI355X."""
 
     GROUP_BYTES = 1 << 30  # packed pixels per mme_embed call (pinned staging + device copy stay bounded)
+    TILE_GROUP_CROPS = 32  # crops per pass of the tile-ViT option (15 MB of f32 pixel values and ~230 MB of workspace each)
 
     def __init__(self, model_name=config.DEFAULT_MODEL_NAME, device=None, gpu_count=None, *, weights=None,
-                 seed: int = 1, pool: str = "cls", chunk: int | None = None, engine: Engine | None = None, devices=None):
+                 seed: int = 1, pool: str = "cls", chunk: int | None = None, engine: Engine | None = None, devices=None,
+                 encoder: str = "vit_b16", geometry=None):
         import torch
 
         self.torch = torch
@@ -124,14 +126,25 @@ class RegionEmbedder:
         self.gpu_count = len(dev_list)
         self.devices = [f"cuda:{d}" for d in dev_list]
         self.device = torch.device(self.devices[0])
+        if encoder not in ("vit_b16", "mllama_tiles"):
+            raise ValueError("encoder must be 'vit_b16' (BASELINE.json's re-scoped ViT-B/16) or 'mllama_tiles' (the checkpoint's own vision-tower geometry)")
+        self.encoder = encoder
         if engine is not None:
             self.engines = [engine]
         else:
-            w = weights if weights is not None else make_vit_weights(seed)
+            if encoder == "mllama_tiles":
+                from .weights import make_tile_vit_weights
+
+                w = weights if weights is not None else (make_tile_vit_weights(seed + 1, geometry) if geometry else make_tile_vit_weights(seed + 1))
+            else:
+                w = weights if weights is not None else make_vit_weights(seed)
             self.engines = []
             for d in dev_list:  # one context (weights + workspace) per device, as embedder.py:73-82
                 e = Engine(d)
-                e.load_vit(w)
+                if encoder == "mllama_tiles":
+                    e.load_tile_vit(w, geometry)
+                else:
+                    e.load_vit(w)
                 self.engines.append(e)
         self.engine = self.engines[0]
         if chunk:
@@ -209,7 +222,11 @@ class RegionEmbedder:
                 return
             try:
                 pix, offs, hw = self.pack([a for _, a in group], device)
-                e32, _ = engine.embed(pix, offs, hw, self.pool_token, want_bf16=False)
+                if self.encoder == "mllama_tiles":  # processor (K1 multi-tile) + vision tower, class token of tile 0 (7680-d)
+                    pv, ids, _, nt = engine.preprocess_tiles(pix, offs, hw, 560, 4)
+                    _, e32, _ = engine.tile_vit_forward(pv, ids, nt, want_bf16=False)
+                else:
+                    e32, _ = engine.embed(pix, offs, hw, self.pool_token, want_bf16=False)
                 rows = e32.cpu().tolist()
                 results.extend((i, row) for (i, _), row in zip(group, rows))
             except Exception as e:  # embedder.py:223-224
@@ -217,6 +234,8 @@ class RegionEmbedder:
                 results.extend((i, None) for i, _ in group)
 
         step = max(1, int(self._group_crops))
+        if getattr(self, "encoder", "vit_b16") == "mllama_tiles":
+            step = min(step, self.TILE_GROUP_CROPS)
         for g0 in range(0, len(items), step):
             part = items[g0 : g0 + step]
             # PNG decode is the slow part of a call (the GPU needs ~3 ms for 48 crops) and Pillow releases the GIL
