@@ -222,7 +222,7 @@ class RegionEmbedder:
                 return
             try:
                 pix, offs, hw = self.pack([a for _, a in group], device)
-                if self.encoder == "mllama_tiles":  # processor (K1 multi-tile) + vision tower, class token of tile 0 (7680-d)
+                if getattr(self, "encoder", "vit_b16") == "mllama_tiles":  # processor (K1 multi-tile) + vision tower, class token of tile 0 (7680-d)
                     pv, ids, _, nt = engine.preprocess_tiles(pix, offs, hw, 560, 4)
                     _, e32, _ = engine.tile_vit_forward(pv, ids, nt, want_bf16=False)
                 else:
