@@ -304,7 +304,7 @@ void fit_to_canvas(int h, int w, int* nh, int* nw) {
 int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const int32_t* hw, int n, bf16_t* patches, hipStream_t s) {
     c->h_crops.resize(n);
     c->h_work.clear();
-    size_t tmp_bytes = 0;
+    size_t tmp_bytes = 0, tab_bytes = 0;
     int table_ints = 16, band_bytes = 16;  // LDS needs of the horizontal pass for this batch
     constexpr int kBand = 32 * 1024;
     bool any_resize = false;
@@ -319,6 +319,7 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
         fit_to_canvas(h, w, &d.new_h, &d.new_w);
         if (h != VIT_IMG || w != VIT_IMG) any_resize = true;
         d.tmp_off = 0;
+        d.tab_off = 0;
         if (d.new_w != w) {
             d.tmp_off = (int64_t)tmp_bytes;
             tmp_bytes += ((size_t)h * d.new_w * 3 + 15) & ~(size_t)15;
@@ -327,6 +328,8 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
             rows = rows < 1 ? 1 : (rows > 64 ? 64 : rows);
             for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
             const int kstride = 2 * ((w + d.new_w - 1) / d.new_w) + 1;
+            d.tab_off = (int64_t)tab_bytes;  // {xmin, n} pairs + coefficients, 16-byte aligned blocks
+            tab_bytes += ((size_t)d.new_w * (8 + (size_t)kstride * 4) + 31) & ~(size_t)15;
             if (d.new_w * kstride > table_ints) table_ints = d.new_w * kstride;
             const int bb = (rows < h ? rows : h) * row_bytes;
             if (bb > band_bytes) band_bytes = bb;
@@ -335,6 +338,7 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     int r;
     if ((r = ensure(c, c->crops, (size_t)n * sizeof(CropDesc)))) return r;
     if ((r = ensure(c, c->tmp, tmp_bytes + 16))) return r;
+    if ((r = ensure(c, c->htab, tab_bytes + 16))) return r;
     if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
     // pageable-host copies: the runtime stages them before returning, so the host vectors
     // may be reused by the next chunk
@@ -342,8 +346,9 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     if (!c->h_work.empty())
         HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
     Timed t(c, s, KC_PRE);
+    if (!c->h_work.empty()) HIP_TRY(c, launch_h_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
     HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
-                               table_ints, band_bytes, s));
+                               table_ints, band_bytes, (const uint8_t*)c->htab.p, s));
     HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, any_resize, s));
     return MME_OK;
 }
@@ -389,7 +394,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->htab, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -719,7 +724,7 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
     c->h_crops.resize(n);
     c->h_work.clear();
     std::vector<int32_t> grid((size_t)n * 2);
-    size_t tmp_bytes = 0;
+    size_t tmp_bytes = 0, tab_bytes = 0;
     int table_ints = 16, band_bytes = 16, taps_cap = 224;
     constexpr int kBand = 32 * 1024;
     for (int i = 0; i < n; ++i) {
@@ -735,6 +740,7 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
         d.w = w;
         fit_to_tile_canvas(h, w, th * tile, tw * tile, tile, &d.new_h, &d.new_w);
         d.tmp_off = 0;
+        d.tab_off = 0;
         if (aspect_ids_host) {  // 1 + index of (th, tw) in the supported list (image_processing_pil_mllama.py:136-164)
             int idx = 0, found = 0;
             for (int a = 1; a <= max_tiles && !found; ++a)
@@ -754,6 +760,8 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
             rows = rows < 1 ? 1 : (rows > 64 ? 64 : rows);
             for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
             const int kstride = 2 * ((w + d.new_w - 1) / d.new_w) + 1;
+            d.tab_off = (int64_t)tab_bytes;  // {xmin, n} pairs + coefficients, 16-byte aligned blocks
+            tab_bytes += ((size_t)d.new_w * (8 + (size_t)kstride * 4) + 31) & ~(size_t)15;
             if (d.new_w * kstride > table_ints) table_ints = d.new_w * kstride;
             const int bb = (rows < h ? rows : h) * row_bytes;
             if (bb > band_bytes) band_bytes = bb;
@@ -764,6 +772,7 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
     const size_t desc_bytes = ((size_t)n * sizeof(CropDesc) + 15) & ~(size_t)15;
     if ((r = ensure(c, c->crops, desc_bytes + grid.size() * sizeof(int32_t)))) return r;
     if ((r = ensure(c, c->tmp, tmp_bytes + 16))) return r;
+    if ((r = ensure(c, c->htab, tab_bytes + 16))) return r;
     if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
     HIP_TRY(c, hipMemcpyAsync(c->crops.p, c->h_crops.data(), (size_t)n * sizeof(CropDesc), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync((char*)c->crops.p + desc_bytes, grid.data(), grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -771,8 +780,9 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
         HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipStreamSynchronize(s));  // `grid` is a local: its staging copy must be done before it goes away
     Timed t(c, s, KC_PRE);
+    if (!c->h_work.empty()) HIP_TRY(c, launch_h_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
     hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
-                                   table_ints, band_bytes, s, taps_cap);
+                                   table_ints, band_bytes, (const uint8_t*)c->htab.p, s, taps_cap);
     if (e != hipSuccess) return fail(c, MME_E_HIP, "mme_preprocess_tiles: horizontal pass (%s); a %d-wide canvas row of a very wide crop exceeds the LDS budget", hipGetErrorString(e), taps_cap);
     HIP_TRY(c, launch_resize_v_tiles(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const int32_t*)((char*)c->crops.p + desc_bytes),
                                      n, c->lut, out, tile, max_tiles, s));

@@ -82,14 +82,18 @@ hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned 
 struct CropDesc {  // one per crop, built on the host by capi
     int64_t src_off;   // byte offset into pix
     int64_t tmp_off;   // byte offset into the horizontal-pass scratch (if used)
+    int64_t tab_off;   // byte offset (16-aligned) of this crop's horizontal tap table in the table buffer (if the width changes)
     int32_t h, w;      // source size
     int32_t new_h, new_w;
 };
 struct HWork {  // one block of the horizontal pass: a band of source rows of one crop
     int32_t crop, row0, nrows;
 };
+// horizontal tap tables (window + 22-bit fixed-point coefficients per output column), once per crop: tab + crop.tab_off holds
+// new_w {xmin, n} pairs followed by new_w * kstride ints, kstride = 2 * ceil(w / new_w) + 1
+hipError_t launch_h_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s);
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
-                           int band_bytes, hipStream_t s, int taps_cap = 224);
+                           int band_bytes, const uint8_t* tab, hipStream_t s, int taps_cap = 224);
 // multi-tile Mllama output: grid_of int32[n,2] (tiles_h, tiles_w); out f32 [n, max_tiles, 3, T, T]
 hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, const int32_t* grid_of, int n,
                                  const float* lut, float* out, int T, int max_tiles, hipStream_t s);

@@ -67,12 +67,25 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// Tap tables of the horizontal pass, ONCE per crop.  A band workgroup used to recompute its crop's table (f64 loops over
+// up to 2 * scale + 1 taps per output column: ~3 k cycles, more than the filtering of a 2-row band of a wide page region
+// costs); now it copies the table from L2 with 16-byte loads.
+__global__ __launch_bounds__(256) void h_tables(const CropDesc* __restrict__ crops, uint8_t* __restrict__ tab) {
+    const CropDesc c = crops[blockIdx.x];
+    if (c.new_w == c.w) return;
+    const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;
+    Taps* taps = (Taps*)(tab + c.tab_off);
+    int* kk = (int*)(taps + c.new_w);
+    for (int x = threadIdx.x; x < c.new_w; x += 256) taps[x] = compute_taps(c.w, c.new_w, x, kk + x * kstride);
+}
+
 // Horizontal pass.  One workgroup = one band of source rows of one crop; the band is a single
 // contiguous byte range (rows are contiguous), fetched with one sweep of 16-byte loads into LDS
 // (all loads in flight at once), then every (row, x, channel) output of the band is computed
 // from LDS in parallel.  Band height is chosen on the host so that a band is <= H_BAND bytes.
 __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
-                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work, int table_ints, int taps_cap) {
+                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work, int table_ints, int taps_cap,
+                                                const uint8_t* __restrict__ tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HWork wk = work[blockIdx.x];
     const CropDesc c = crops[wk.crop];
@@ -83,7 +96,14 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
     int* kk = (int*)(smem + (size_t)taps_cap * sizeof(Taps));
     uint8_t* band = (uint8_t*)(smem + (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int));
     const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;  // >= 2*ceil(max(scale,1))+1
-    for (int x = tid; x < c.new_w; x += 256) taps[x] = compute_taps(c.w, c.new_w, x, kk + x * kstride);
+    {   // the crop's precomputed table (h_tables): {xmin, n} pairs, then the coefficients -- two 16-byte-aligned sweeps
+        const uint4* gt = (const uint4*)(tab + c.tab_off);
+        const int ntap_vec = (c.new_w * (int)sizeof(Taps) + 15) >> 4;
+        for (int i = tid; i < ntap_vec; i += 256) ((uint4*)taps)[i] = gt[i];
+        // (the coefficient block starts 8 * new_w bytes in: 16-byte aligned only for even new_w -> copy as 8-byte words)
+        const uint2* gk = (const uint2*)(tab + c.tab_off + (size_t)c.new_w * sizeof(Taps));
+        for (int i = tid; i < (c.new_w * kstride * 4 + 7) >> 3; i += 256) ((uint2*)kk)[i] = gk[i];
+    }
     const uint8_t* src = pix + c.src_off + (int64_t)wk.row0 * row_bytes;
     const int nbytes = wk.nrows * row_bytes;
     const uintptr_t a0 = (uintptr_t)src & ~(uintptr_t)15;
@@ -94,23 +114,37 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
     const uint8_t* bb = band + lead;
     const int out_row = c.new_w * 3;
     uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * out_row;
-    // one output PIXEL per thread: the three channels share the tap window and every coefficient read
-    for (int e = tid; e < wk.nrows * c.new_w; e += 256) {
+    // one output PIXEL COLUMN per thread for a PAIR of rows (y, y + half): the six sums share every coefficient read and give
+    // the LDS byte reads of one row something independent to overlap with
+    const int half = (wk.nrows + 1) >> 1;
+    for (int e = tid; e < half * c.new_w; e += 256) {
         const int y = e / c.new_w, xx = e - y * c.new_w;
+        const int y2 = y + half;
+        const bool two = y2 < wk.nrows;
         const Taps t = taps[xx];
         const int* k = kk + xx * kstride;
-        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0, u0 = s0, u1 = s0, u2 = s0;
         const uint8_t* p = bb + y * row_bytes + t.xmin * 3;
+        const uint8_t* p2 = two ? p + half * row_bytes : p;
         for (int x = 0; x < t.n; ++x) {
             const int w = k[x];
             s0 += (int)p[x * 3] * w;
             s1 += (int)p[x * 3 + 1] * w;
             s2 += (int)p[x * 3 + 2] * w;
+            u0 += (int)p2[x * 3] * w;
+            u1 += (int)p2[x * 3 + 1] * w;
+            u2 += (int)p2[x * 3 + 2] * w;
         }
-        uint8_t* o = dst + (int64_t)e * 3;
+        uint8_t* o = dst + ((int64_t)y * c.new_w + xx) * 3;
         o[0] = clip8(s0);
         o[1] = clip8(s1);
         o[2] = clip8(s2);
+        if (two) {
+            uint8_t* o2 = dst + ((int64_t)y2 * c.new_w + xx) * 3;
+            o2[0] = clip8(u0);
+            o2[1] = clip8(u1);
+            o2[2] = clip8(u2);
+        }
     }
 }
 
@@ -302,15 +336,21 @@ hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const C
     return hipGetLastError();
 }
 
+hipError_t launch_h_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(h_tables, dim3(n), dim3(256), 0, s, crops, tab);
+    return hipGetLastError();
+}
+
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
-                           int band_bytes, hipStream_t s, int taps_cap) {
+                           int band_bytes, const uint8_t* tab, hipStream_t s, int taps_cap) {
     if (nwork <= 0) return hipSuccess;
     // Taps table + coefficient table (largest of the batch) + one band (+ alignment slack)
     if (taps_cap < VIT_IMG) taps_cap = VIT_IMG;
     const size_t smem = (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int) + (size_t)band_bytes + 48;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = ensure_dynamic_lds((const void*)resize_h, (int)smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints, taps_cap);
+    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints, taps_cap, tab);
     return hipGetLastError();
 }
 
