@@ -172,6 +172,14 @@ int mme_normalise_rows(mme_ctx* ctx, const float* x_dev, int64_t rows, int d, ui
 int mme_cosine(mme_ctx* ctx, const uint16_t* a_dev, int m, const uint16_t* b_dev, int n, int d,
                float* sim_dev, int64_t ld_sim, void* stream);
 
+/* The same block with S rounded to bf16 (round-to-nearest-even of the f32 accumulator: |error| <= 2^-9 relative, i.e.
+ * <= 0.002 on a cosine): halves the bytes the compare stage writes and the next stage reads -- the [8192 x 65536] block of
+ * one rank of config C4 is 1.07 GB instead of 2.15 GB.  n % 4 == 0 and ld_sim % 8 == 0 (16-byte stores).  Ranking
+ * consumers that must match the f32 order (K10 / K12) keep using the f32 values; this is the output option for callers
+ * that store or threshold similarities. */
+int mme_cosine_bf16(mme_ctx* ctx, const uint16_t* a_dev, int m, const uint16_t* b_dev, int n, int d, uint16_t* sim_dev, int64_t ld_sim,
+                    void* stream);
+
 /* ---- K10: segmented top-k + area-weighted page reduction ---------------------------------
  * Replaces the page-pair loop of compute_image_similarity_matrix
  * (weighted_region_clustering.py:162-252).  Regions are grouped by page:

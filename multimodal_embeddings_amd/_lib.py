@@ -72,6 +72,7 @@ EXPORTS = {
     "mme_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_normalise_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_cosine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mme_cosine_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "mme_page_similarity": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_page_similarity_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
@@ -366,6 +367,18 @@ class Engine:
             out = t.empty((m, n), dtype=t.float32, device=a.device)
         assert a.dtype == t.bfloat16 and b.dtype == t.bfloat16 and a.is_contiguous() and b.is_contiguous()
         self._check(self.lib.mme_cosine(self.h, a.data_ptr(), m, b.data_ptr(), n, d, out.data_ptr(), out.stride(0), self._stream()), "mme_cosine")
+        return out
+
+    def cosine_bf16(self, a, b=None, out=None):
+        """as `cosine`, S rounded to bf16 (mme_cosine_bf16): half the bytes; bit-equal to `cosine(...).to(bfloat16)`."""
+        t = self.torch
+        b = a if b is None else b
+        m, d = a.shape
+        n = b.shape[0]
+        if out is None:
+            out = t.empty((m, (n + 7) // 8 * 8), dtype=t.bfloat16, device=a.device)[:, :n]
+        assert a.dtype == t.bfloat16 and b.dtype == t.bfloat16 and a.is_contiguous() and b.is_contiguous() and out.dtype == t.bfloat16
+        self._check(self.lib.mme_cosine_bf16(self.h, a.data_ptr(), m, b.data_ptr(), n, d, out.data_ptr(), out.stride(0), self._stream()), "mme_cosine_bf16")
         return out
 
     def page_similarity(self, emb, area_pct, valid, page_offs, skip=None, *, max_query=10, top_k=10, max_dist=0.9, metric=0, normalise=True,

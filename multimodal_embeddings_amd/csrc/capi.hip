@@ -394,7 +394,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->htab, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->htab, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws, &c->zero_bias};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -578,6 +578,27 @@ int mme_cosine(mme_ctx* c, const uint16_t* a, int m, const uint16_t* b, int n, i
     GemmArgs g{};
     g.A = a; g.W = b; g.M = m; g.N = n; g.K = d; g.outf = sim; g.ldf = ld;
     HIP_TRY(c, launch_gemm(EPI_F32, g, s, c->gemm_variant));
+    return MME_OK;
+}
+
+int mme_cosine_bf16(mme_ctx* c, const uint16_t* a, int m, const uint16_t* b, int n, int d, uint16_t* sim, int64_t ld, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (m < 0 || n < 0 || d <= 0 || (d % 64) != 0) return fail(c, MME_E_ARG, "mme_cosine_bf16: m,n >= 0 and d %% 64 == 0 required (d=%d)", d);
+    if (m == 0 || n == 0) return MME_OK;
+    if (!a || !b || !sim || ld < n || (ld % 8) != 0 || (n % 4) != 0)
+        return fail(c, MME_E_ARG, "mme_cosine_bf16: null pointer, ld_sim < n, ld_sim %% 8 != 0 or n %% 4 != 0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the bf16 epilogues add a bias vector: a resident row of zeros (acc + 0.0f is exact), grown on demand
+    if (c->zero_bias.bytes < (size_t)n * sizeof(float)) {
+        int r = ensure(c, c->zero_bias, ((size_t)n * sizeof(float) + 4095) & ~(size_t)4095);
+        if (r) return r;
+        HIP_TRY(c, hipMemsetAsync(c->zero_bias.p, 0, c->zero_bias.bytes, s));
+    }
+    Timed t(c, s, KC_COS);
+    GemmArgs g{};
+    g.A = a; g.W = b; g.M = m; g.N = n; g.K = d; g.bias = (const float*)c->zero_bias.p; g.out = sim; g.ldo = ld;
+    HIP_TRY(c, launch_gemm(EPI_BIAS, g, s, c->gemm_variant));
     return MME_OK;
 }
 

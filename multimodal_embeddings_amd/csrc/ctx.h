@@ -51,7 +51,7 @@ struct mme_ctx {
     float* lut = nullptr;  // [3,256]
     // workspace (sized for `chunk` crops)
     int ws_chunk = 0;
-    DevBuf x, hbuf, qkv, att, mlp, stats, lnpart, patches, tmp, htab, crops, hwork, page_ws, cluster_ws, neigh_ws;
+    DevBuf x, hbuf, qkv, att, mlp, stats, lnpart, patches, tmp, htab, crops, hwork, page_ws, cluster_ws, neigh_ws, zero_bias;
     // host staging for crop tables
     std::vector<CropDesc> h_crops;
     std::vector<HWork> h_work;

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
                                                              unsigned long long* stamps = nullptr) {
     constexpr bool DEFER = NDEF > 0;
         static_assert(NDEF == 0 || NDEF == 4 || NDEF == 6 || NDEF == 8, "NDEF");
-    static_assert(!DEFER || epi_has_fast_path<EPI>(), "DEFER needs a 16-byte fast-path epilogue");
+    static_assert(!DEFER || epi_has_fast_path<EPI>() || (EPI == EPI_F32 && NDEF == 4), "DEFER needs a 16-byte fast-path epilogue");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,8 +144,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
     const int pend_lo0 = fr * (int)g.ldo + row16_col(0, fq), pend_lo1 = fr * (int)g.ldo + row16_col(2, fq);
     auto pend_store = [&](auto idx_tag) {
         constexpr int IDX = decltype(idx_tag)::value;  // (i - (8 - NDEF / 2)) * 2 + (jp >> 1)
-        if constexpr (DEFER && IDX < NDEF)
-            *(uint4*)(pend_base + (int64_t)(8 - NDEF / 2 + (IDX >> 1)) * 16 * g.ldo + ((IDX & 1) ? pend_lo1 : pend_lo0)) = pend[IDX];
+        if constexpr (DEFER && IDX < NDEF) {
+            if constexpr (EPI == EPI_F32) {  // f32 out: the four column tiles j = IDX of the last row block (i = 7)
+                float* fb = (float*)pend_base;
+                *(uint4*)(fb + (int64_t)(7 * 16 + fr) * g.ldf + IDX * 16 + fq * 4) = pend[IDX];
+            } else {
+                *(uint4*)(pend_base + (int64_t)(8 - NDEF / 2 + (IDX >> 1)) * 16 * g.ldo + ((IDX & 1) ? pend_lo1 : pend_lo0)) = pend[IDX];
+            }
+        }
     };
     // pending stores issued in phase q of the carrying K-tile: 4 -> 1,1,1,1   6 -> 2,2,1,1   8 -> 2,2,2,2
     constexpr int PQ0 = NDEF >= 6 ? 2 : 1, PQ1 = NDEF >= 6 ? 2 : 1, PQ2 = NDEF >= 8 ? 2 : 1;
@@ -304,7 +310,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         // store issued before it: all loads (bias, residual, positions) are issued first, with
         // row indices clamped instead of branched, and the stores are fire-and-forget.
         const bool fast = EPI != EPI_F32 && EPI != EPI_TOPK && n0 + TN <= g.N && m0 + TM <= g.M;
-        if (fast) {
+        // f32 out (K9 cosine block): interior tiles of a 16-byte-aligned, ld % 4 == 0 matrix store straight-line as well --
+        // 32 fire-and-forget 16-byte stores per lane instead of 32 guarded ones with a wait after each
+        const bool fast_f32 = EPI == EPI_F32 && n0 + TN <= g.N && m0 + TM <= g.M && (g.ldf & 3) == 0 && ((uintptr_t)g.outf & 15) == 0;
+        if (EPI == EPI_F32 && fast_f32) {
+            float* fb = g.outf + (int64_t)(m0 + wm * 128) * g.ldf + n0 + wn * 64;  // wave-uniform
+            const int64_t lo = (int64_t)fr * g.ldf + fq * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (DEFER && i == 7) {
+                        pend[j < (DEFER ? NDEF : 1) ? j : 0] = __builtin_bit_cast(uint4, acc[i][j]);
+                    } else {
+                        *(f32x4*)(fb + (int64_t)i * 16 * g.ldf + lo + j * 16) = acc[i][j];
+                    }
+                }
+            if (DEFER) pend_base = (bf16_t*)fb;
+        } else if (fast) {
             // interior tile: straight-line code, no per-lane predicate (a branch would make the
             // compiler re-insert vmcnt(0) -- i.e. a wait for the stores -- at every join)
             if constexpr (EPI == EPI_PATCH) {
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
                         }
                 }
             } else {
-                if constexpr (DEFER) {
+                if constexpr (DEFER && epi_has_fast_path<EPI>()) {
                     epilogue_wave_128x64<EPI, NDEF>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {}, pend);
                     pend_base = (bf16_t*)g.out + (int64_t)(m0 + wm * 128) * g.ldo + (n0 + wn * 64);
                 } else if constexpr (epi_has_fast_path<EPI>()) {
@@ -498,6 +521,7 @@ hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int d
             default: break;
         }
     } else if (defer == 4) {
+        if (epilogue == EPI_F32) return launch256r<EPI_F32, 4>(g, s);
         switch (epilogue) {
             case EPI_BIAS: return launch256r<EPI_BIAS, 4>(g, s);
             case EPI_BIAS_GELU: return launch256r<EPI_BIAS_GELU, 4>(g, s);

@@ -208,11 +208,11 @@ def test_embed_chunking_and_ragged_batch(engine):
     assert e0.shape == (0, 768)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_cosine_matches_f64(engine, variant):
     engine.set_gemm_variant(variant)
     rng = np.random.default_rng(2)
-    for m, n, d in [(1, 1, 64), (5, 300, 768), (257, 129, 768), (1000, 1000, 128), (130, 4100, 768)]:
+    for m, n, d in [(1, 1, 64), (5, 300, 768), (257, 129, 768), (1000, 1000, 128), (130, 4100, 768), (1024, 2304, 768), (777, 1028, 128)]:
         a = rng.standard_normal((m, d)).astype(np.float32)
         b = rng.standard_normal((n, d)).astype(np.float32)
         ta = engine.normalise_rows(torch.from_numpy(a).cuda())
@@ -222,6 +222,10 @@ def test_cosine_matches_f64(engine, variant):
         fa, fb = ta.float().cpu().numpy().astype(np.float64), tb.float().cpu().numpy().astype(np.float64)
         want = fa @ fb.T
         assert np.abs(sim.cpu().numpy() - want).max() <= 2e-6, (m, n, d)
+        if n % 4 == 0:  # the bf16-S option is the round-to-nearest-even of the f32 block, bit for bit (|error| <= 2^-9 relative)
+            s16 = engine.cosine_bf16(ta, tb)
+            assert torch.equal(s16, sim.to(torch.bfloat16)), (m, n, d)
+            assert float((s16.float() - sim).abs().max()) <= 2.0 ** -9
         # normalise_rows itself: unit rows, rounding of the f32 normalisation
         ref = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12)
         assert np.abs(fa - ref).max() <= 2.0 ** -8
@@ -240,7 +244,7 @@ def test_gemm_variants_bit_identical_and_race_free(engine, golden_dir):
         b = engine.normalise_rows(torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).cuda())
         engine.set_gemm_variant(1)
         ref = engine.cosine(a, b)
-        for variant in (2, 3):
+        for variant in (2, 3, 4):  # 4: the last row block of a wave tile is stored from inside the next tile's K loop
             engine.set_gemm_variant(variant)
             for _ in range(reps):
                 got = engine.cosine(a, b)

@@ -33,9 +33,17 @@ def main():
     e16 = eng.normalise_rows(torch.randn(n, d, generator=g, device="cuda") + centres[torch.randint(0, 40, (n,), generator=g, device="cuda")])
     rows = n // 8
     sim = torch.empty((rows, n), dtype=torch.float32, device="cuda")
-    dt, _ = timed(lambda: eng.cosine(e16[:rows], e16, out=sim))
     wr, fl = rows * n * 4.0, 2.0 * rows * n * d
-    print(f"K9  cosine row block [{rows} x {n}] f32: {dt*1e3:.3f} ms  write {wr/dt/1e12:.2f} TB/s (+{n*d*2/1e6:.0f} MB read)  {fl/dt/1e12:.0f} TFLOP/s", flush=True)
+    for variant, name in ((3, "all stores in the epilogue"), (4, "last row block deferred into the next tile's K loop (default)")):
+        eng.set_gemm_variant(variant)
+        dt, _ = timed(lambda: eng.cosine(e16[:rows], e16, out=sim), reps=10)
+        print(f"K9  cosine row block [{rows} x {n}] f32, variant {variant} ({name}): {dt*1e3:.3f} ms  write {wr/dt/1e12:.2f} TB/s = {wr/dt/8e12*100:.1f} % of 8 TB/s "
+              f"(+{n*d*2/1e6:.0f} MB read)  {fl/dt/1e12:.0f} TFLOP/s", flush=True)
+    eng.set_gemm_variant(0)
+    sim16 = torch.empty((rows, n), dtype=torch.bfloat16, device="cuda")
+    dt, _ = timed(lambda: eng.cosine_bf16(e16[:rows], e16, out=sim16), reps=10)
+    print(f"K9  the same block with S as bf16 (mme_cosine_bf16): {dt*1e3:.3f} ms  write {wr/2/dt/1e12:.2f} TB/s  {fl/dt/1e12:.0f} TFLOP/s", flush=True)
+    del sim16
     rng = np.random.default_rng(8)
     area = np.exp(rng.uniform(np.log(1e-2), np.log(20.0), n))
     valid = np.ones(n, np.uint8)
