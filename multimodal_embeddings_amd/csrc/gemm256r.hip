@@ -45,7 +45,7 @@ constexpr int LDS_BYTES = 3 * ASLOT + 2 * BSLOT;
 // next tile's first K-tile.
 template <int EPI, bool STAMP = false, int NDEF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tiles_m, int tiles_n, int gn, int dbg,
-                                                             unsigned long long* stamps = nullptr) {
+                                                             unsigned long long* stamps = nullptr, int rb = 0) {
     constexpr bool DEFER = NDEF > 0;
         static_assert(NDEF == 0 || NDEF == 4 || NDEF == 6 || NDEF == 8, "NDEF");
     static_assert(!DEFER || epi_has_fast_path<EPI>() || (EPI == EPI_F32 && NDEF == 4), "DEFER needs a 16-byte fast-path epilogue");
@@ -78,11 +78,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         TileCtx c;
         // ids are ordered (column group, row panel, column in group): an XCD's contiguous id range
         // stays inside one group of `gn` column tiles, whose weight rows then live in its L2
+        // rb > 0: the row panels are cut into blocks of rb and the column groups alternate INSIDE a block, so the second
+        // group re-reads a block of A panels (rb x 256 rows) a few hundred tiles after the first read it -- from the
+        // Infinity Cache -- instead of after the whole activation matrix has streamed through
         const int id = xcd_remap(tile, ntiles);
-        const int gsz = tiles_m * gn;
-        const int grp = id / gsz, rem = id - grp * gsz;
+        const int rbs = rb > 0 ? rb : tiles_m;
+        const int per_blk = rbs * tiles_n;
+        const int blk = id / per_blk, idb = id - blk * per_blk;
+        const int rows_blk = min(rbs, tiles_m - blk * rbs);
+        const int gsz = rows_blk * gn;
+        const int grp = idb / gsz, rem = idb - grp * gsz;
         const int gw = min(gn, tiles_n - grp * gn);
-        const int tm = rem / gw, tn = grp * gn + (rem - tm * gw);
+        const int tm = blk * rbs + rem / gw, tn = grp * gn + (rem - (rem / gw) * gw);
         c.m0 = tm * TM;
         c.n0 = tn * TN;
         c.Ag = (const char*)g.A + (size_t)((dbg & 3) == 2 ? 0 : c.m0) * ldb;
@@ -471,8 +478,12 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     int gn = gn_env > 0 ? gn_env : (int)((2400 * 1024) / ((size_t)TN * g.K * 2));
     if (gn < 3) gn = 3;
     if (gn > tiles_n) gn = tiles_n;
+    // MME_GEMM_RB: row-panel block of the tile order (0 = one block: column group outermost; default 16 when the columns
+    // form more than one group); read per launch for A/B runs
+    const char* rb_env = getenv("MME_GEMM_RB");
+    const int rb = rb_env ? atoi(rb_env) : (tiles_n > gn ? 16 : 0);  // measured 4096 crops: 16 -> -0.4 % GEMM time, 8 / 32 -> +-0
     hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI, false, DEFER>), dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, gn, dbg,
-                       (unsigned long long*)nullptr);
+                       (unsigned long long*)nullptr, rb);
     return hipGetLastError();
 }
 
