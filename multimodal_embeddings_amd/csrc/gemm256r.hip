@@ -478,10 +478,11 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     int gn = gn_env > 0 ? gn_env : (int)((2400 * 1024) / ((size_t)TN * g.K * 2));
     if (gn < 3) gn = 3;
     if (gn > tiles_n) gn = tiles_n;
-    // MME_GEMM_RB: row-panel block of the tile order (0 = one block: column group outermost; default 16 when the columns
-    // form more than one group); read per launch for A/B runs
+    // MME_GEMM_RB: row-panel block of the tile order (0 = one block: column group outermost, the default); read per launch for A/B runs
     const char* rb_env = getenv("MME_GEMM_RB");
-    const int rb = rb_env ? atoi(rb_env) : (tiles_n > gn ? 16 : 0);  // measured 4096 crops: 16 -> -0.4 % GEMM time, 8 / 32 -> +-0
+    // measured at 4096 crops: 16 -> -0.4 % GEMM time (8 / 32: +-0) but +5 % requests leaving the L2 (the weight group is
+    // re-fetched per block; FETCH_SIZE counts Infinity-Cache hits too) -- inside the noise, so the default stays 0
+    const int rb = rb_env ? atoi(rb_env) : 0;
     hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI, false, DEFER>), dim3(grid), dim3(512), smem, s, g, tiles_m, tiles_n, gn, dbg,
                        (unsigned long long*)nullptr, rb);
     return hipGetLastError();
