@@ -117,7 +117,7 @@ class RegionCollection:
         Exact brute force on the GPU: the candidates that pass `where` and the query vectors are stacked into one
         table of unit bf16 rows; kernel K12 ranks the query rows against it with the queries' own group masked out
         (so a query never returns itself or another query).  Up to 128 results per query come from K12's streaming
-        selection; larger requests sort a K9 cosine block."""
+        selection (k + number of queries <= 128); larger requests sort a K9 cosine block."""
         from .cross_compare import to_unit_bf16
 
         if query_embeddings is None or len(query_embeddings) == 0:
@@ -145,11 +145,13 @@ class RegionCollection:
         else:
             cand = table
         q = to_unit_bf16(query_embeddings, engine)
-        if k <= 128:
+        if k + nq <= 128:
+            # K12 keeps the best `fetch` rows BEFORE it drops the query's own group: the nq query rows of the stacked
+            # table (the query itself at cosine 1, possibly the other queries) may all rank inside, so fetch k + nq
             stacked = t.cat([cand, q], dim=0)
             group = t.zeros(n_c + nq, dtype=t.int32, device=stacked.device)
             group[n_c:] = 1
-            idx, sim = engine.neighbours(stacked, group, row0=n_c, nrows=nq, fetch=k, top_n=k)
+            idx, sim = engine.neighbours(stacked, group, row0=n_c, nrows=nq, fetch=k + nq, top_n=k)
         else:
             block = engine.cosine(q, cand)
             order = t.sort(block, dim=1, descending=True, stable=True)
