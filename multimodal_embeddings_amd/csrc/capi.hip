@@ -301,12 +301,62 @@ void fit_to_canvas(int h, int w, int* nh, int* nw) {
     }
 }
 
+// K1 plan shared by the two preprocessing entry points: scratch image + resampling tables of every crop and the bands of
+// the horizontal pass.  A band is a whole number of K1_H_RPT-row groups.  Crops whose row group fits kBandSmall bytes
+// (w <= 2048) form the first launch (24 KiB of LDS: six workgroups per CU); wider crops get one row group per band in a
+// second launch whose LDS is sized for the widest of them.
+struct K1Plan {
+    size_t tmp_bytes = 0, tab_bytes = 0;
+    std::vector<HWork> large;  // (the small bands go straight into ctx->h_work)
+    int band_small = 16, band_large = 16, n_small = 0;
+};
+constexpr int kBandSmall = 24 * 1024;
+
+void plan_crop(mme_ctx* c, K1Plan& p, int i, CropDesc& d) {
+    d.tmp_off = 0;
+    d.tab_off = (int64_t)p.tab_bytes;
+    p.tab_bytes += (size_t)k1_layout(d.h, d.w, d.new_h, d.new_w).bytes;
+    if (d.new_w == d.w) return;
+    d.tmp_off = (int64_t)p.tmp_bytes;
+    p.tmp_bytes += (size_t)d.h * k1_tmp_pitch(d.new_w);
+    const int row_bytes = d.w * 3;
+    int rows = (kBandSmall / row_bytes) & ~(K1_H_RPT - 1);
+    const bool small = rows >= K1_H_RPT;
+    rows = small ? (rows > 64 ? 64 : rows) : K1_H_RPT;
+    std::vector<HWork>& list = small ? c->h_work : p.large;
+    for (int r = 0; r < d.h; r += rows) list.push_back(HWork{i, r, (d.h - r) < rows ? (d.h - r) : rows});
+    const int bb = (rows < d.h ? rows : d.h) * row_bytes;
+    int& cap = small ? p.band_small : p.band_large;
+    if (bb > cap) cap = bb;
+}
+
+// copies the band list to the device and runs resample_tables + the horizontal pass (both launches)
+int run_h_pass(mme_ctx* c, K1Plan& p, const uint8_t* pix, int n, hipStream_t s, const char* who) {
+    p.n_small = (int)c->h_work.size();
+    c->h_work.insert(c->h_work.end(), p.large.begin(), p.large.end());
+    int r;
+    if ((r = ensure(c, c->tmp, p.tmp_bytes + 16))) return r;
+    if ((r = ensure(c, c->htab, p.tab_bytes + 16))) return r;
+    if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
+    if (!c->h_work.empty())
+        HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
+    return MME_OK;
+}
+int launch_h_pass(mme_ctx* c, const K1Plan& p, const uint8_t* pix, int n, hipStream_t s, const char* who) {
+    if (p.tab_bytes) HIP_TRY(c, launch_resample_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
+    const HWork* work = (const HWork*)c->hwork.p;
+    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work, p.n_small, p.band_small, (const uint8_t*)c->htab.p, s));
+    const int n_large = (int)c->h_work.size() - p.n_small;
+    hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work + p.n_small, n_large, p.band_large,
+                                   (const uint8_t*)c->htab.p, s);
+    if (e != hipSuccess) return fail(c, MME_E_HIP, "%s: horizontal pass (%s); band of %d bytes", who, hipGetErrorString(e), p.band_large);
+    return MME_OK;
+}
+
 int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const int32_t* hw, int n, bf16_t* patches, hipStream_t s) {
     c->h_crops.resize(n);
     c->h_work.clear();
-    size_t tmp_bytes = 0, tab_bytes = 0;
-    int table_ints = 16, band_bytes = 16;  // LDS needs of the horizontal pass for this batch
-    constexpr int kBand = 32 * 1024;
+    K1Plan plan;
     bool any_resize = false;
     for (int i = 0; i < n; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
@@ -318,38 +368,18 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
         d.w = w;
         fit_to_canvas(h, w, &d.new_h, &d.new_w);
         if (h != VIT_IMG || w != VIT_IMG) any_resize = true;
-        d.tmp_off = 0;
-        d.tab_off = 0;
-        if (d.new_w != w) {
-            d.tmp_off = (int64_t)tmp_bytes;
-            tmp_bytes += ((size_t)h * d.new_w * 3 + 15) & ~(size_t)15;
-            const int row_bytes = w * 3;
-            int rows = kBand / row_bytes;
-            rows = rows < 1 ? 1 : (rows > 64 ? 64 : rows);
-            for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
-            const int kstride = 2 * ((w + d.new_w - 1) / d.new_w) + 1;
-            d.tab_off = (int64_t)tab_bytes;  // {xmin, n} pairs + coefficients, 16-byte aligned blocks
-            tab_bytes += ((size_t)d.new_w * (8 + (size_t)kstride * 4) + 31) & ~(size_t)15;
-            if (d.new_w * kstride > table_ints) table_ints = d.new_w * kstride;
-            const int bb = (rows < h ? rows : h) * row_bytes;
-            if (bb > band_bytes) band_bytes = bb;
-        }
+        plan_crop(c, plan, i, d);
     }
     int r;
     if ((r = ensure(c, c->crops, (size_t)n * sizeof(CropDesc)))) return r;
-    if ((r = ensure(c, c->tmp, tmp_bytes + 16))) return r;
-    if ((r = ensure(c, c->htab, tab_bytes + 16))) return r;
-    if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
     // pageable-host copies: the runtime stages them before returning, so the host vectors
     // may be reused by the next chunk
     HIP_TRY(c, hipMemcpyAsync(c->crops.p, c->h_crops.data(), (size_t)n * sizeof(CropDesc), hipMemcpyHostToDevice, s));
-    if (!c->h_work.empty())
-        HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
+    if ((r = run_h_pass(c, plan, pix, n, s, "mme_preprocess"))) return r;
     Timed t(c, s, KC_PRE);
-    if (!c->h_work.empty()) HIP_TRY(c, launch_h_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
-    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
-                               table_ints, band_bytes, (const uint8_t*)c->htab.p, s));
-    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, any_resize, s));
+    if ((r = launch_h_pass(c, plan, pix, n, s, "mme_preprocess"))) return r;
+    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, any_resize,
+                                        (const uint8_t*)c->htab.p, s));
     return MME_OK;
 }
 
@@ -745,9 +775,7 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
     c->h_crops.resize(n);
     c->h_work.clear();
     std::vector<int32_t> grid((size_t)n * 2);
-    size_t tmp_bytes = 0, tab_bytes = 0;
-    int table_ints = 16, band_bytes = 16, taps_cap = 224;
-    constexpr int kBand = 32 * 1024;
+    K1Plan plan;
     for (int i = 0; i < n; ++i) {
         const int h = hw[2 * i], w = hw[2 * i + 1];
         if (h <= 0 || w <= 0 || h > 8000 || w > 8000) return fail(c, MME_E_ARG, "crop %d has size %dx%d (h x w); supported 1..8000", i, h, w);
@@ -760,8 +788,6 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
         d.h = h;
         d.w = w;
         fit_to_tile_canvas(h, w, th * tile, tw * tile, tile, &d.new_h, &d.new_w);
-        d.tmp_off = 0;
-        d.tab_off = 0;
         if (aspect_ids_host) {  // 1 + index of (th, tw) in the supported list (image_processing_pil_mllama.py:136-164)
             int idx = 0, found = 0;
             for (int a = 1; a <= max_tiles && !found; ++a)
@@ -773,38 +799,17 @@ int mme_preprocess_tiles(mme_ctx* c, const uint8_t* pix, const int64_t* offs, co
             aspect_ids_host[i] = found;
         }
         if (num_tiles_host) num_tiles_host[i] = th * tw;
-        if (d.new_w != w) {
-            d.tmp_off = (int64_t)tmp_bytes;
-            tmp_bytes += ((size_t)h * d.new_w * 3 + 15) & ~(size_t)15;
-            const int row_bytes = w * 3;
-            int rows = kBand / row_bytes;
-            rows = rows < 1 ? 1 : (rows > 64 ? 64 : rows);
-            for (int r = 0; r < h; r += rows) c->h_work.push_back(HWork{i, r, (h - r) < rows ? (h - r) : rows});
-            const int kstride = 2 * ((w + d.new_w - 1) / d.new_w) + 1;
-            d.tab_off = (int64_t)tab_bytes;  // {xmin, n} pairs + coefficients, 16-byte aligned blocks
-            tab_bytes += ((size_t)d.new_w * (8 + (size_t)kstride * 4) + 31) & ~(size_t)15;
-            if (d.new_w * kstride > table_ints) table_ints = d.new_w * kstride;
-            const int bb = (rows < h ? rows : h) * row_bytes;
-            if (bb > band_bytes) band_bytes = bb;
-            if (d.new_w > taps_cap) taps_cap = d.new_w;
-        }
+        plan_crop(c, plan, i, d);
     }
     int r;
     const size_t desc_bytes = ((size_t)n * sizeof(CropDesc) + 15) & ~(size_t)15;
     if ((r = ensure(c, c->crops, desc_bytes + grid.size() * sizeof(int32_t)))) return r;
-    if ((r = ensure(c, c->tmp, tmp_bytes + 16))) return r;
-    if ((r = ensure(c, c->htab, tab_bytes + 16))) return r;
-    if ((r = ensure(c, c->hwork, (c->h_work.size() + 1) * sizeof(HWork)))) return r;
     HIP_TRY(c, hipMemcpyAsync(c->crops.p, c->h_crops.data(), (size_t)n * sizeof(CropDesc), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemcpyAsync((char*)c->crops.p + desc_bytes, grid.data(), grid.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    if (!c->h_work.empty())
-        HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
+    if ((r = run_h_pass(c, plan, pix, n, s, "mme_preprocess_tiles"))) return r;
     HIP_TRY(c, hipStreamSynchronize(s));  // `grid` is a local: its staging copy must be done before it goes away
     Timed t(c, s, KC_PRE);
-    if (!c->h_work.empty()) HIP_TRY(c, launch_h_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
-    hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const HWork*)c->hwork.p, (int)c->h_work.size(),
-                                   table_ints, band_bytes, (const uint8_t*)c->htab.p, s, taps_cap);
-    if (e != hipSuccess) return fail(c, MME_E_HIP, "mme_preprocess_tiles: horizontal pass (%s); a %d-wide canvas row of a very wide crop exceeds the LDS budget", hipGetErrorString(e), taps_cap);
+    if ((r = launch_h_pass(c, plan, pix, n, s, "mme_preprocess_tiles"))) return r;
     HIP_TRY(c, launch_resize_v_tiles(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, (const int32_t*)((char*)c->crops.p + desc_bytes),
                                      n, c->lut, out, tile, max_tiles, s));
     return MME_OK;

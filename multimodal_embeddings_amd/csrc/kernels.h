@@ -81,19 +81,43 @@ hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned 
 
 struct CropDesc {  // one per crop, built on the host by capi
     int64_t src_off;   // byte offset into pix
-    int64_t tmp_off;   // byte offset into the horizontal-pass scratch (if used)
-    int64_t tab_off;   // byte offset (16-aligned) of this crop's horizontal tap table in the table buffer (if the width changes)
+    int64_t tmp_off;   // byte offset (16-aligned) into the horizontal-pass scratch (if the width changes)
+    int64_t tab_off;   // byte offset (16-aligned) of this crop's resampling tables in the table buffer (K1Layout)
     int32_t h, w;      // source size
     int32_t new_h, new_w;
 };
 struct HWork {  // one block of the horizontal pass: a band of source rows of one crop
     int32_t crop, row0, nrows;
 };
-// horizontal tap tables (window + 22-bit fixed-point coefficients per output column), once per crop: tab + crop.tab_off holds
-// new_w {xmin, n} pairs followed by new_w * kstride ints, kstride = 2 * ceil(w / new_w) + 1
-hipError_t launch_h_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s);
-hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
-                           int band_bytes, const uint8_t* tab, hipStream_t s, int taps_cap = 224);
+// Row pitch of the horizontal pass's scratch image: rows start 16-byte aligned so the vertical pass reads them as dwords
+// (four adjacent output bytes per LDS read) and stages them with 16-byte copies.
+__host__ __device__ inline int k1_tmp_pitch(int new_w) { return (new_w * 3 + 15) & ~15; }
+// Resampling tables of one crop (resample_tables), at tab + crop.tab_off:
+//   width changes:  Taps[new_w] {xmin, n} | pad to 16 | uint4 hk[gh][new_w]   -- coefficients in groups of four taps,
+//                   group-major so that adjacent output columns read adjacent 16-byte words; zero beyond tap n
+//   height changes: Taps[new_h] | pad to 16 | int vk[new_h][kv]               -- zero beyond tap n
+// gh * 4, kv >= 2 * ceil(scale) + 1 = Resample.c's ksize, the upper bound of n.
+struct K1Layout {
+    int gh, kv;
+    int64_t hk_off, vt_off, vk_off, bytes;
+};
+__host__ __device__ inline K1Layout k1_layout(int h, int w, int new_h, int new_w) {
+    K1Layout L;
+    const bool hp = new_w != w, vp = new_h != h;
+    L.gh = hp ? (2 * ((w + new_w - 1) / new_w) + 1 + 3) >> 2 : 0;
+    L.kv = vp ? ((2 * ((h + new_h - 1) / new_h) + 1 + 3) & ~3) : 0;
+    L.hk_off = hp ? (((int64_t)new_w * 8 + 15) & ~(int64_t)15) : 0;
+    L.vt_off = L.hk_off + (int64_t)L.gh * new_w * 16;
+    L.vk_off = L.vt_off + (vp ? (((int64_t)new_h * 8 + 15) & ~(int64_t)15) : 0);
+    L.bytes = (L.vk_off + (int64_t)new_h * L.kv * 4 + 15) & ~(int64_t)15;
+    return L;
+}
+constexpr int K1_H_RPT = 4;  // source rows one thread of the horizontal pass filters (bands are whole groups of them)
+// both tap tables of every crop, once per crop (f64 on the device exactly as Resample.c computes them on the host)
+hipError_t launch_resample_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s);
+// horizontal pass over `nwork` bands; band_bytes = the largest band (nrows * w * 3) among them
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int band_bytes,
+                           const uint8_t* tab, hipStream_t s);
 // multi-tile Mllama output: grid_of int32[n,2] (tiles_h, tiles_w); out f32 [n, max_tiles, 3, T, T]
 hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, const int32_t* grid_of, int n,
                                  const float* lut, float* out, int T, int max_tiles, hipStream_t s);
@@ -101,7 +125,7 @@ hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const C
 hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* boxes, const int64_t* offs, const HWork* work, int nwork,
                              uint8_t* pix, hipStream_t s);
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
-                                    const float* lut /*[3,256]*/, void* patches, bool any_resize, hipStream_t s);
+                                    const float* lut /*[3,256]*/, void* patches, bool any_resize, const uint8_t* tab, hipStream_t s);
 
 struct PageSimArgs {
     const void* emb;        // bf16 [N, d]

@@ -9,14 +9,22 @@
 //
 // HBM-bound byte work (no MFMA): reads are 16-byte coalesced row streams staged through LDS,
 // the patch matrix is written as whole 1536-byte patch rows.
-//   resize_h          one workgroup per (crop, band of source rows): source row -> LDS,
-//                     fixed-point taps from an LDS coefficient table -> uint8 scratch row.
-//   resize_v_patchify one workgroup per (crop, patch row): vertical taps (or a plain copy
-//                     when the height is unchanged, e.g. the 224x224 synthetic crops) into a
-//                     16 x 224 x 3 uint8 LDS canvas, then LUT-normalise and emit 14 patches.
+//   resample_tables   one workgroup per crop: both tap tables (window + coefficients per output coordinate), f64 as
+//                     Resample.c, laid out for the two passes (K1Layout, kernels.h).
+//   resize_h          one workgroup per (crop, band of source rows): band -> LDS with 16-byte loads; a thread filters
+//                     one output pixel column of FOUR rows: per group of four taps one 16-byte coefficient word (L1 / L2)
+//                     and one 12-byte LDS read per row (4 pixels x RGB), 48 24-bit multiply-adds; the three result bytes
+//                     of four neighbouring lanes are exchanged inside the quad (DPP) and leave as dword stores into a
+//                     scratch image whose rows are 16-byte aligned.
+//   resize_v_patchify one workgroup per (crop, patch row): the source-row window of the 16-row canvas band goes through
+//                     an LDS window in chunks; a thread owns four adjacent canvas bytes of one row (one dword LDS read
+//                     per tap, accumulators in registers across chunks); then LUT-normalise and emit 14 patches.
 //
-// Coefficients are computed on the device in f64 exactly as Resample.c does on the host;
-// contraction is disabled so no fused multiply-add changes a rounding.
+// The fixed-point sums are exact in 32-bit unsigned arithmetic: triangle weights are >= 0 and sum to 2^22 +- n/2, so
+// 255 * sum + 2^21 < 2^31, and v_mad_u32_u24 multiplies an 8-bit pixel by a < 2^24 coefficient exactly.
+// Contraction is disabled so no fused multiply-add changes a rounding of the f64 coefficient arithmetic.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -26,15 +34,19 @@ namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
 constexpr int MAX_TAPS = 160;      // window <= 2*ceil(scale)+1 and scale < 2*MAX_DIM/224
-constexpr int V_WINDOW = 36 * 1024; // bytes of source rows a resize_v workgroup stages in LDS
+constexpr int V_KMAX = MAX_TAPS;   // vertical taps per output row kept in LDS (a 1..15-row output of an extreme aspect ratio reaches 2 * 72 + 1)
 
 struct Taps {
     int xmin, n;
 };
+struct __attribute__((packed)) Pix12 {  // 4 RGB pixels at ANY byte address (gfx950 reads unaligned LDS words)
+    uint32_t a, b, c;
+};
 
 // One output coordinate's window and fixed-point weights (Resample.c precompute_coeffs +
-// normalize_coeffs_8bpc, bilinear filter, box = whole image).
-__device__ __forceinline__ Taps compute_taps(int in_size, int out_size, int xx, int* kk /*[MAX_TAPS]*/) {
+// normalize_coeffs_8bpc, bilinear filter, box = whole image).  store(i, k) receives tap i's coefficient.
+template <class Store>
+__device__ __forceinline__ Taps compute_taps_to(int in_size, int out_size, int xx, Store store) {
     const double scale = (double)in_size / (double)out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
     const double support = 1.0 * filterscale;
@@ -57,103 +69,165 @@ __device__ __forceinline__ Taps compute_taps(int in_size, int out_size, int xx, 
         if (t < 0.0) t = -t;
         double w = t < 1.0 ? 1.0 - t : 0.0;
         if (ww != 0.0) w /= ww;
-        kk[x] = w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS));
+        store(x, w < 0 ? (int)(-0.5 + w * (double)(1 << PRECISION_BITS)) : (int)(0.5 + w * (double)(1 << PRECISION_BITS)));
     }
     return Taps{xmin, n};
+}
+__device__ __forceinline__ Taps compute_taps(int in_size, int out_size, int xx, int* kk /*[MAX_TAPS]*/) {
+    return compute_taps_to(in_size, out_size, xx, [&](int i, int k) { kk[i] = k; });
 }
 
 __device__ __forceinline__ uint8_t clip8(int v) {
     v >>= PRECISION_BITS;
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
+__device__ __forceinline__ uint32_t clip8u(uint32_t v) {
+    v >>= PRECISION_BITS;
+    return v > 255u ? 255u : v;
+}
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
 
-// Tap tables of the horizontal pass, ONCE per crop.  A band workgroup used to recompute its crop's table (f64 loops over
-// up to 2 * scale + 1 taps per output column: ~3 k cycles, more than the filtering of a 2-row band of a wide page region
-// costs); now it copies the table from L2 with 16-byte loads.
-__global__ __launch_bounds__(256) void h_tables(const CropDesc* __restrict__ crops, uint8_t* __restrict__ tab) {
+// Contiguous 16-byte-aligned global range -> LDS by LDS-DMA: every wave instruction moves 64 x 16 bytes to
+// (wave-uniform base) + lane * 16 with nothing staged in registers, all requests in flight at once (a register-staged
+// copy loop waits for each load before it stores: one global latency per 4 KiB).  Lanes past the end re-read the last
+// vector into up to 1008 bytes of slack behind the range, which the caller's LDS allocation includes (DMA_SLACK).
+constexpr int DMA_SLACK = 1024;
+__device__ __forceinline__ void dma_range_to_lds(const uint4* __restrict__ g, char* lds, int nvec, int tid) {
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int i = wave * 64; i < nvec; i += 256) glds16(g + min(i + lane, nvec - 1), lds + (size_t)i * 16);
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Both tap tables of a crop, ONCE per crop (a band / patch-row workgroup used to recompute its own: f64 loops over up to
+// 2 * scale + 1 taps per output coordinate, ~3 k cycles, more than filtering a small band costs).
+__global__ __launch_bounds__(256) void resample_tables(const CropDesc* __restrict__ crops, uint8_t* __restrict__ tab) {
     const CropDesc c = crops[blockIdx.x];
-    if (c.new_w == c.w) return;
-    const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;
-    Taps* taps = (Taps*)(tab + c.tab_off);
-    int* kk = (int*)(taps + c.new_w);
-    for (int x = threadIdx.x; x < c.new_w; x += 256) taps[x] = compute_taps(c.w, c.new_w, x, kk + x * kstride);
+    const K1Layout L = k1_layout(c.h, c.w, c.new_h, c.new_w);
+    uint8_t* base = tab + c.tab_off;
+    if (c.new_w != c.w) {
+        Taps* taps = (Taps*)base;
+        int* hk = (int*)(base + L.hk_off);
+        for (int x = threadIdx.x; x < c.new_w; x += 256) {
+            const Taps t = compute_taps_to(c.w, c.new_w, x, [&](int i, int k) { hk[((int64_t)(i >> 2) * c.new_w + x) * 4 + (i & 3)] = k; });
+            for (int i = t.n; i < L.gh * 4; ++i) hk[((int64_t)(i >> 2) * c.new_w + x) * 4 + (i & 3)] = 0;
+            taps[x] = t;
+        }
+    }
+    if (c.new_h != c.h) {
+        Taps* taps = (Taps*)(base + L.vt_off);
+        int* vk = (int*)(base + L.vk_off);
+        for (int y = threadIdx.x; y < c.new_h; y += 256) {
+            int* row = vk + (int64_t)y * L.kv;
+            const Taps t = compute_taps_to(c.h, c.new_h, y, [&](int i, int k) { row[i] = k; });
+            for (int i = t.n; i < L.kv; ++i) row[i] = 0;
+            taps[y] = t;
+        }
+    }
 }
 
-// Horizontal pass.  One workgroup = one band of source rows of one crop; the band is a single
-// contiguous byte range (rows are contiguous), fetched with one sweep of 16-byte loads into LDS
-// (all loads in flight at once), then every (row, x, channel) output of the band is computed
-// from LDS in parallel.  Band height is chosen on the host so that a band is <= H_BAND bytes.
+// Horizontal pass.  One workgroup = one band of source rows of one crop (a whole number of K1_H_RPT-row groups except at
+// the crop's end); the band is a single contiguous byte range, fetched with one sweep of 16-byte loads into LDS (all loads
+// in flight at once).  Work item = (row group, output column): lanes of a quad are four neighbouring columns.
 __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
-                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work, int table_ints, int taps_cap,
+                                                const CropDesc* __restrict__ crops, const HWork* __restrict__ work,
                                                 const uint8_t* __restrict__ tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const HWork wk = work[blockIdx.x];
     const CropDesc c = crops[wk.crop];
     const int tid = threadIdx.x;
     const int row_bytes = c.w * 3;
-    // LDS carve: [taps_cap] Taps (>= widest output row of the batch) | coefficient table (per-launch size) | band
-    Taps* taps = (Taps*)smem;
-    int* kk = (int*)(smem + (size_t)taps_cap * sizeof(Taps));
-    uint8_t* band = (uint8_t*)(smem + (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int));
-    const int kstride = 2 * ((c.w + c.new_w - 1) / c.new_w) + 1;  // >= 2*ceil(max(scale,1))+1
-    {   // the crop's precomputed table (h_tables): {xmin, n} pairs, then the coefficients -- two 16-byte-aligned sweeps
-        const uint4* gt = (const uint4*)(tab + c.tab_off);
-        const int ntap_vec = (c.new_w * (int)sizeof(Taps) + 15) >> 4;
-        for (int i = tid; i < ntap_vec; i += 256) ((uint4*)taps)[i] = gt[i];
-        // (the coefficient block starts 8 * new_w bytes in: 16-byte aligned only for even new_w -> copy as 8-byte words)
-        const uint2* gk = (const uint2*)(tab + c.tab_off + (size_t)c.new_w * sizeof(Taps));
-        for (int i = tid; i < (c.new_w * kstride * 4 + 7) >> 3; i += 256) ((uint2*)kk)[i] = gk[i];
-    }
+    const Taps* __restrict__ taps = (const Taps*)(tab + c.tab_off);
+    const uint4* __restrict__ hk = (const uint4*)(tab + c.tab_off + (((int64_t)c.new_w * 8 + 15) & ~(int64_t)15));
+    uint8_t* band = (uint8_t*)smem;
     const uint8_t* src = pix + c.src_off + (int64_t)wk.row0 * row_bytes;
     const int nbytes = wk.nrows * row_bytes;
     const uintptr_t a0 = (uintptr_t)src & ~(uintptr_t)15;
     const int lead = (int)((uintptr_t)src - a0);
     const int nvec = (lead + nbytes + 15) >> 4;
-    for (int i = tid; i < nvec; i += 256) ((uint4*)band)[i] = ((const uint4*)a0)[i];
+    dma_range_to_lds((const uint4*)a0, (char*)band, nvec, tid);
+    const int xw = (c.new_w + 3) & ~3;  // columns rounded up to whole quads (the extra lanes repeat the last column)
+    const int nrg = (wk.nrows + K1_H_RPT - 1) / K1_H_RPT;
+    const int nitems = nrg * xw;
+    // the first item's window and coefficients travel while the band lands
+    int e = tid;
+    int rg = e / xw, xq = e - rg * xw, xx = min(xq, c.new_w - 1);
+    Taps t = e < nitems ? taps[xx] : Taps{0, 0};
+    uint4 k0 = e < nitems ? hk[xx] : uint4{0, 0, 0, 0};
+    dma_wait_all();
     __syncthreads();
     const uint8_t* bb = band + lead;
-    const int out_row = c.new_w * 3;
-    uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * out_row;
-    // one output PIXEL COLUMN per thread for a PAIR of rows (y, y + half): the six sums share every coefficient read and give
-    // the LDS byte reads of one row something independent to overlap with
-    const int half = (wk.nrows + 1) >> 1;
-    for (int e = tid; e < half * c.new_w; e += 256) {
-        const int y = e / c.new_w, xx = e - y * c.new_w;
-        const int y2 = y + half;
-        const bool two = y2 < wk.nrows;
-        const Taps t = taps[xx];
-        const int* k = kk + xx * kstride;
-        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0, u0 = s0, u1 = s0, u2 = s0;
-        const uint8_t* p = bb + y * row_bytes + t.xmin * 3;
-        const uint8_t* p2 = two ? p + half * row_bytes : p;
-        for (int x = 0; x < t.n; ++x) {
-            const int w = k[x];
-            s0 += (int)p[x * 3] * w;
-            s1 += (int)p[x * 3 + 1] * w;
-            s2 += (int)p[x * 3 + 2] * w;
-            u0 += (int)p2[x * 3] * w;
-            u1 += (int)p2[x * 3 + 1] * w;
-            u2 += (int)p2[x * 3 + 2] * w;
+    const int pitch = k1_tmp_pitch(c.new_w);
+    uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * pitch;
+    const int j = tid & 3;  // position in the quad (256 and xw are multiples of 4: quads never straddle items' rows)
+    while (e < nitems) {
+        const int y0 = rg * K1_H_RPT;
+        const int ng = (t.n + 3) >> 2;
+        const uint8_t* p[K1_H_RPT];
+#pragma unroll
+        for (int r = 0; r < K1_H_RPT; ++r) p[r] = bb + min(y0 + r, wk.nrows - 1) * row_bytes + t.xmin * 3;
+        uint32_t acc[K1_H_RPT][3];
+#pragma unroll
+        for (int r = 0; r < K1_H_RPT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1u << (PRECISION_BITS - 1);
+        uint4 k = k0;
+        // next item's window + first coefficient group: independent of this item's arithmetic
+        const int e_n = e + 256;
+        const int rg_n = e_n / xw, xq_n = e_n - rg_n * xw, xx_n = min(xq_n, c.new_w - 1);
+        Taps t_n = Taps{0, 0};
+        if (e_n < nitems) {
+            t_n = taps[xx_n];
+            k0 = hk[xx_n];
         }
-        uint8_t* o = dst + ((int64_t)y * c.new_w + xx) * 3;
-        o[0] = clip8(s0);
-        o[1] = clip8(s1);
-        o[2] = clip8(s2);
-        if (two) {
-            uint8_t* o2 = dst + ((int64_t)y2 * c.new_w + xx) * 3;
-            o2[0] = clip8(u0);
-            o2[1] = clip8(u1);
-            o2[2] = clip8(u2);
+        for (int g = 0; g < ng; ++g) {
+            const uint4 kn = g + 1 < ng ? hk[(int64_t)(g + 1) * c.new_w + xx] : uint4{0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < K1_H_RPT; ++r) {
+                const Pix12 d = *(const Pix12*)(p[r] + g * 12);
+                acc[r][0] = mad24(d.a & 0xff, k.x, acc[r][0]);
+                acc[r][1] = mad24((d.a >> 8) & 0xff, k.x, acc[r][1]);
+                acc[r][2] = mad24((d.a >> 16) & 0xff, k.x, acc[r][2]);
+                acc[r][0] = mad24(d.a >> 24, k.y, acc[r][0]);
+                acc[r][1] = mad24(d.b & 0xff, k.y, acc[r][1]);
+                acc[r][2] = mad24((d.b >> 8) & 0xff, k.y, acc[r][2]);
+                acc[r][0] = mad24((d.b >> 16) & 0xff, k.z, acc[r][0]);
+                acc[r][1] = mad24(d.b >> 24, k.z, acc[r][1]);
+                acc[r][2] = mad24(d.c & 0xff, k.z, acc[r][2]);
+                acc[r][0] = mad24((d.c >> 8) & 0xff, k.w, acc[r][0]);
+                acc[r][1] = mad24((d.c >> 16) & 0xff, k.w, acc[r][1]);
+                acc[r][2] = mad24(d.c >> 24, k.w, acc[r][2]);
+            }
+            k = kn;
         }
+        // lanes j = 0..2 of a quad write the quad's 12 output bytes as three dwords
+        const int o = (xq & ~3) * 3 + 4 * j;
+#pragma unroll
+        for (int r = 0; r < K1_H_RPT; ++r) {
+            const uint32_t v = clip8u(acc[r][0]) | (clip8u(acc[r][1]) << 8) | (clip8u(acc[r][2]) << 16);
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF9 /* quad_perm [1,2,3,3] */, 0xF, 0xF, true);
+            const uint32_t out = j == 0 ? (v | (nb << 24)) : (j == 1 ? ((v >> 8) | (nb << 16)) : ((v >> 16) | (nb << 8)));
+            if (j < 3 && y0 + r < wk.nrows && o < c.new_w * 3) *(uint32_t*)(dst + (int64_t)(y0 + r) * pitch + o) = out;
+        }
+        e = e_n;
+        rg = rg_n;
+        xq = xq_n;
+        xx = xx_n;
+        t = t_n;
     }
 }
 
+// Vertical pass + zero pad + normalise + patchify.  Three forms of the canvas fill:
+//   (a) unchanged 224-wide rows (the synthetic 224 x 224 workload): one contiguous 10752-byte band, 16-byte copies;
+//   (b) the source is the horizontal pass's scratch image (16-byte aligned rows): dword path below;
+//   (c) the width was not resized (rows of the packed crop at any alignment; rare): byte reads straight from global.
+// RESIZE = false: the instantiation for batches of 224 x 224 crops only (form (b) compiled out: half the registers, so the
+// pure stream keeps its occupancy).
+template <bool RESIZE>
 __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
                                                          const CropDesc* __restrict__ crops, const float* __restrict__ lut,
-                                                         bf16_t* __restrict__ patches, int window_bytes) {
-    __shared__ __attribute__((aligned(16))) uint8_t canvas[VIT_PATCH * VIT_IMG * 3 + 16];
+                                                         bf16_t* __restrict__ patches, const uint8_t* __restrict__ tab, int window_bytes) {
+    constexpr int ROW = VIT_IMG * 3, ROW4 = ROW / 4, NIT = (VIT_PATCH * ROW4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) uint8_t canvas[VIT_PATCH * ROW + 16];
     __shared__ Taps taps[VIT_PATCH];
-    __shared__ int kk[VIT_PATCH * MAX_TAPS];
+    __shared__ int kk[VIT_PATCH * V_KMAX];
     __shared__ float slut[3 * 256];
     extern __shared__ __attribute__((aligned(16))) uint8_t window[];  // source rows feeding this band (0 bytes for all-224 batches)
     const int crop = blockIdx.x / VIT_GRID, py = blockIdx.x - crop * VIT_GRID;
@@ -162,65 +236,94 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
     for (int i = tid; i < 768; i += 256) slut[i] = lut[i];
     const bool hpass = c.new_w != c.w;       // Resample.c: horizontal pass only when width changes
     const bool vpass = c.new_h != c.h;
-    const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
     const int src_row_bytes = c.new_w * 3;   // after the horizontal pass (or unchanged width)
-    if (vpass && tid < VIT_PATCH) {
-        const int yy = py * VIT_PATCH + tid;
-        if (yy < c.new_h) taps[tid] = compute_taps(c.h, c.new_h, yy, kk + tid * MAX_TAPS);
-    }
-    __syncthreads();
-    // fill the 16-row canvas band: resized pixels, zero outside (pad precedes normalisation)
-    const uint8_t* band = src + (int64_t)py * VIT_PATCH * src_row_bytes;
-    if (!vpass && src_row_bytes == VIT_IMG * 3 && (py + 1) * VIT_PATCH <= c.new_h && (((uintptr_t)band) & 15) == 0) {
-        // unchanged 224-wide rows (the synthetic 224x224 workload): one contiguous 10752-byte band
-        for (int e = tid; e < VIT_PATCH * VIT_IMG * 3 / 16; e += 256) ((uint4*)canvas)[e] = ((const uint4*)band)[e];
-    } else
-    {
-        // vertical pass (or row copy): the source rows this band needs form one contiguous byte
-        // range; stage it in LDS with 16-byte loads when it fits, else read global directly
-        const int y_first = py * VIT_PATCH, y_last = min(y_first + VIT_PATCH, c.new_h) - 1;
-        int r0 = 0, r1 = -1;  // source row range [r0, r1]
-        if (y_last >= y_first) {
-            if (vpass) {
-                r0 = taps[0].xmin;
-                r1 = taps[y_last - y_first].xmin + taps[y_last - y_first].n - 1;
-            } else {
-                r0 = y_first;
-                r1 = y_last;
+    const int y_first = py * VIT_PATCH, nout = min(y_first + VIT_PATCH, c.new_h) - y_first;  // canvas rows with pixels (may be <= 0)
+    if (nout > 0) {
+        if (vpass) {  // this band's 16 windows and coefficient rows from the crop's table
+            const K1Layout L = k1_layout(c.h, c.w, c.new_h, c.new_w);
+            const Taps* vt = (const Taps*)(tab + c.tab_off + L.vt_off);
+            const int* vk = (const int*)(tab + c.tab_off + L.vk_off);
+            if (tid < nout) taps[tid] = vt[y_first + tid];
+            for (int i = tid; i < nout * L.kv; i += 256) {
+                const int ky = i / L.kv, x = i - ky * L.kv;
+                kk[ky * V_KMAX + x] = vk[(int64_t)(y_first + ky) * L.kv + x];
+            }
+        } else {  // no vertical pass: a one-tap "filter" with weight 1.0 copies exactly ((p << 22) + (1 << 21)) >> 22 == p
+            if (tid < nout) {
+                taps[tid] = Taps{y_first + tid, 1};
+                kk[tid * V_KMAX] = 1 << PRECISION_BITS;
             }
         }
-        const int64_t wbytes = (int64_t)(r1 - r0 + 1) * src_row_bytes;
-        const uint8_t* wsrc = src + (int64_t)r0 * src_row_bytes;
-        const bool staged = wbytes > 0 && wbytes <= window_bytes;
-        int lead = 0;
-        if (staged) {
-            const uintptr_t a0 = (uintptr_t)wsrc & ~(uintptr_t)15;
-            lead = (int)((uintptr_t)wsrc - a0);
-            const int nvec = (int)((lead + wbytes + 15) >> 4);
-            for (int i = tid; i < nvec; i += 256) ((uint4*)window)[i] = ((const uint4*)a0)[i];
-        }
-        __syncthreads();
-        const uint8_t* wb = window + lead;
-        for (int e = tid; e < VIT_PATCH * VIT_IMG * 3; e += 256) {
-            const int ky = e / (VIT_IMG * 3), rem = e - ky * (VIT_IMG * 3);
-            const int yy = py * VIT_PATCH + ky;
-            uint8_t v = 0;
-            if (yy < c.new_h && rem < src_row_bytes) {
-                if (!vpass) {
-                    v = staged ? wb[(yy - r0) * src_row_bytes + rem] : src[(int64_t)yy * src_row_bytes + rem];
-                } else {
+    }
+    __syncthreads();
+    const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
+    const uint8_t* band = src + (int64_t)y_first * src_row_bytes;
+    if (!vpass && src_row_bytes == ROW && nout == VIT_PATCH && (((uintptr_t)band) & 15) == 0) {  // (a); scratch rows of 672 bytes are contiguous too
+        for (int e = tid; e < VIT_PATCH * ROW / 16; e += 256) ((uint4*)canvas)[e] = ((const uint4*)band)[e];
+    } else if (RESIZE && hpass && nout > 0 && window_bytes > 0) {
+        const int pitch = k1_tmp_pitch(c.new_w), pitch4 = pitch >> 2;
+        const int ncol4 = (src_row_bytes + 3) >> 2;
+        const int r0 = taps[0].xmin, r1 = taps[nout - 1].xmin + taps[nout - 1].n;  // source rows [r0, r1)
+        const int rows_chunk = max(window_bytes / pitch, 1);
+        uint32_t acc[NIT][4];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 1u << (PRECISION_BITS - 1);
+        const uint32_t* win = (const uint32_t*)window;
+        for (int c0 = r0; c0 < r1; c0 += rows_chunk) {
+            const int c1 = min(c0 + rows_chunk, r1);
+            if (c0 != r0) __syncthreads();  // every read of the previous chunk is done
+            const uint4* g = (const uint4*)(src + (int64_t)c0 * pitch);
+            dma_range_to_lds(g, (char*)window, (c1 - c0) * (pitch >> 4), tid);
+            dma_wait_all();
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const int e = tid + 256 * i;
+                const int ky = e / ROW4, c4 = e - ky * ROW4;
+                if (ky < nout && c4 < ncol4) {
                     const Taps t = taps[ky];
-                    const int* k = kk + ky * MAX_TAPS;
-                    int ss0 = 1 << (PRECISION_BITS - 1);
-                    if (staged) {
-                        const uint8_t* p = wb + (t.xmin - r0) * src_row_bytes + rem;
-                        for (int y = 0; y < t.n; ++y) ss0 += (int)p[y * src_row_bytes] * k[y];
-                    } else {
-                        const uint8_t* p = src + (int64_t)t.xmin * src_row_bytes + rem;
-                        for (int y = 0; y < t.n; ++y) ss0 += (int)p[(int64_t)y * src_row_bytes] * k[y];
+                    const int lo = max(t.xmin, c0), hi = min(t.xmin + t.n, c1);
+                    const uint32_t* wp = win + (lo - c0) * pitch4 + c4;
+                    const int* kp = kk + ky * V_KMAX + (lo - t.xmin);
+                    for (int y = 0; y < hi - lo; ++y) {
+                        const uint32_t d = wp[y * pitch4];
+                        const uint32_t k = (uint32_t)kp[y];
+                        acc[i][0] = mad24(d & 0xff, k, acc[i][0]);
+                        acc[i][1] = mad24((d >> 8) & 0xff, k, acc[i][1]);
+                        acc[i][2] = mad24((d >> 16) & 0xff, k, acc[i][2]);
+                        acc[i][3] = mad24(d >> 24, k, acc[i][3]);
                     }
-                    v = clip8(ss0);
                 }
+            }
+        }
+        // canvas: resized pixels, zero outside (pad precedes normalisation)
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = tid + 256 * i;
+            const int ky = e / ROW4, c4 = e - ky * ROW4;
+            if (ky < VIT_PATCH) {
+                uint32_t v = 0;
+                if (ky < nout) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (c4 * 4 + b < src_row_bytes) v |= clip8u(acc[i][b]) << (8 * b);
+                }
+                ((uint32_t*)canvas)[e] = v;
+            }
+        }
+    } else {
+        // width not resized: rows of the packed crop (any alignment), bytes straight from global; also the all-padding band
+        for (int e = tid; e < VIT_PATCH * ROW; e += 256) {
+            const int ky = e / ROW, rem = e - ky * ROW;
+            uint8_t v = 0;
+            if (ky < nout && rem < src_row_bytes) {
+                const Taps t = taps[ky];
+                const int* k = kk + ky * V_KMAX;
+                const int64_t spitch = hpass ? k1_tmp_pitch(c.new_w) : src_row_bytes;
+                const uint8_t* p = src + (int64_t)t.xmin * spitch + rem;
+                uint32_t ss0 = 1u << (PRECISION_BITS - 1);
+                for (int y = 0; y < t.n; ++y) ss0 = mad24(p[(int64_t)y * spitch], (uint32_t)k[y], ss0);
+                v = (uint8_t)clip8u(ss0);
             }
             canvas[e] = v;
         }
@@ -231,7 +334,7 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
     for (int e = tid; e < VIT_GRID * VIT_D / 8; e += 256) {
         const int px = e / (VIT_D / 8), q = e - px * (VIT_D / 8);
         const int ch = q >> 5, ky = (q >> 1) & 15, kx0 = (q & 1) * 8;
-        const uint8_t* cp = canvas + ky * (VIT_IMG * 3) + (px * VIT_PATCH + kx0) * 3 + ch;
+        const uint8_t* cp = canvas + ky * ROW + (px * VIT_PATCH + kx0) * 3 + ch;
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (bf16_t)slut[ch * 256 + cp[j * 3]];
@@ -270,7 +373,7 @@ __global__ __launch_bounds__(256) void resize_v_tiles(const uint8_t* __restrict_
     const int y0 = ty * T + rb * TILE_ROWS, x0 = tx * T;
     const bool hpass = c.new_w != c.w, vpass = c.new_h != c.h;
     const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
-    const int64_t srb = (int64_t)c.new_w * 3;
+    const int64_t srb = hpass ? (int64_t)k1_tmp_pitch(c.new_w) : (int64_t)c.new_w * 3;  // scratch rows are 16-byte aligned
     if (vpass && tid < TILE_ROWS && y0 + tid < c.new_h) taps[tid] = compute_taps(c.h, c.new_h, y0 + tid, kk + tid * MAX_TAPS);
     __syncthreads();
     for (int e = tid; e < 3 * TILE_ROWS * T; e += 256) {
@@ -285,10 +388,10 @@ __global__ __launch_bounds__(256) void resize_v_tiles(const uint8_t* __restrict_
             } else {
                 const Taps t = taps[r];
                 const int* k = kk + r * MAX_TAPS;
-                int ss0 = 1 << (PRECISION_BITS - 1);
+                uint32_t ss0 = 1u << (PRECISION_BITS - 1);
                 p += t.xmin * srb;
-                for (int y = 0; y < t.n; ++y) ss0 += (int)p[y * srb] * k[y];
-                v = clip8(ss0);
+                for (int y = 0; y < t.n; ++y) ss0 = mad24(p[y * srb], (uint32_t)k[y], ss0);
+                v = (int)clip8u(ss0);
             }
         }
         o[(int64_t)ch * T * T + rem] = slut[ch * 256 + v];
@@ -336,31 +439,33 @@ hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const C
     return hipGetLastError();
 }
 
-hipError_t launch_h_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s) {
+hipError_t launch_resample_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(h_tables, dim3(n), dim3(256), 0, s, crops, tab);
+    hipLaunchKernelGGL(resample_tables, dim3(n), dim3(256), 0, s, crops, tab);
     return hipGetLastError();
 }
 
-hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int table_ints,
-                           int band_bytes, const uint8_t* tab, hipStream_t s, int taps_cap) {
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int band_bytes,
+                           const uint8_t* tab, hipStream_t s) {
     if (nwork <= 0) return hipSuccess;
-    // Taps table + coefficient table (largest of the batch) + one band (+ alignment slack)
-    if (taps_cap < VIT_IMG) taps_cap = VIT_IMG;
-    const size_t smem = (size_t)taps_cap * sizeof(Taps) + (size_t)table_ints * sizeof(int) + (size_t)band_bytes + 48;
+    // one band + alignment lead (<= 15) + vector rounding (<= 15) + the last tap group's over-read (<= 9 bytes, zero weights)
+    const size_t smem = (size_t)band_bytes + 64 + DMA_SLACK;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
     if (hipError_t e = ensure_dynamic_lds((const void*)resize_h, (int)smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, table_ints, taps_cap, tab);
+    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
     return hipGetLastError();
 }
 
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n, const float* lut,
-                                    void* patches, bool any_resize, hipStream_t s) {
+                                    void* patches, bool any_resize, const uint8_t* tab, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     // the LDS window is only needed when some crop is resized or partially fills the canvas; the
     // all-224x224 batch keeps the small footprint (more workgroups per CU for a pure stream)
-    const int window = any_resize ? V_WINDOW : 0;
-    hipLaunchKernelGGL(resize_v_patchify, dim3(n * VIT_GRID), dim3(256), window ? window + 32 : 0, s, pix, tmp, crops, lut,
-                       (bf16_t*)patches, window);
+    static const int win_kb = getenv("MME_K1_VWIN") ? atoi(getenv("MME_K1_VWIN")) : 16;  // tuning switch (KiB per chunk)
+    const int window = any_resize ? (win_kb < 1 ? 1 : (win_kb > 96 ? 96 : win_kb)) * 1024 : 0;
+    if (any_resize)
+        hipLaunchKernelGGL(resize_v_patchify<true>, dim3(n * VIT_GRID), dim3(256), window + DMA_SLACK, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, window);
+    else
+        hipLaunchKernelGGL(resize_v_patchify<false>, dim3(n * VIT_GRID), dim3(256), 0, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, 0);
     return hipGetLastError();
 }

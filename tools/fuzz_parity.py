@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweeps of the GPU kernels against the oracle (run on a GPU box; ~1.5 minutes):
 
-    python tools/fuzz_parity.py
+    python tools/fuzz_parity.py [k1 neighbours fused pages cluster]
 
   k1          480 random crop sizes (tiny, extreme aspect, near 224, large): patches and Mllama tiles bit-exact
   neighbours   60 random (N, D, fetch, top_n, groups, duplicates, score windows): indices and values exact
@@ -185,7 +185,10 @@ def main():
     emb = RegionEmbedder()
     eng = emb.engine
     total = 0
+    only = set(sys.argv[1:])  # e.g. `python tools/fuzz_parity.py k1` runs one sweep
     for name, fn in [("k1", fuzz_k1), ("neighbours", fuzz_neighbours), ("fused", fuzz_fused), ("pages", fuzz_pages), ("cluster", fuzz_cluster)]:
+        if only and name not in only:
+            continue
         t0 = time.time()
         bad = fn(eng, emb)
         print(f"{name}: {bad} mismatches ({time.time() - t0:.1f} s)", flush=True)
