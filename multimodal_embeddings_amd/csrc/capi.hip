@@ -302,30 +302,35 @@ void fit_to_canvas(int h, int w, int* nh, int* nw) {
 }
 
 // K1 plan shared by the two preprocessing entry points: scratch image + resampling tables of every crop and the bands of
-// the horizontal pass.  A band is a whole number of K1_H_RPT-row groups.  Crops whose row group fits kBandSmall bytes
-// (w <= 2048) form the first launch (24 KiB of LDS: six workgroups per CU); wider crops get one row group per band in a
-// second launch whose LDS is sized for the widest of them.
+// the horizontal pass.  A band is a whole number of K1_H_RPT-row groups.  Crops whose table + one row group fit kHLds
+// bytes form the first launch (table in LDS beside the band; five workgroups per CU at 32 KiB); wider crops get one row
+// group per band in a second launch that reads the table through L1 and whose LDS is sized for the widest of them.
 struct K1Plan {
     size_t tmp_bytes = 0, tab_bytes = 0;
     std::vector<HWork> large;  // (the small bands go straight into ctx->h_work)
     int band_small = 16, band_large = 16, n_small = 0;
+    int kv_max = 0;  // largest K1Layout::kv of the batch (LDS of the vertical pass)
 };
-constexpr int kBandSmall = 24 * 1024;
+// MME_K1_HBAND (KiB): tuning switch for the LDS budget of the first launch
+static const int kHLds = (getenv("MME_K1_HBAND") && atoi(getenv("MME_K1_HBAND")) >= 4 ? atoi(getenv("MME_K1_HBAND")) : 32) * 1024;
 
 void plan_crop(mme_ctx* c, K1Plan& p, int i, CropDesc& d) {
     d.tmp_off = 0;
     d.tab_off = (int64_t)p.tab_bytes;
-    p.tab_bytes += (size_t)k1_layout(d.h, d.w, d.new_h, d.new_w).bytes;
+    const K1Layout lay = k1_layout(d.h, d.w, d.new_h, d.new_w);
+    p.tab_bytes += (size_t)lay.bytes;
+    if (lay.kv > p.kv_max) p.kv_max = lay.kv;
     if (d.new_w == d.w) return;
     d.tmp_off = (int64_t)p.tmp_bytes;
     p.tmp_bytes += (size_t)d.h * k1_tmp_pitch(d.new_w);
     const int row_bytes = d.w * 3;
-    int rows = (kBandSmall / row_bytes) & ~(K1_H_RPT - 1);
-    const bool small = rows >= K1_H_RPT;
+    const int tab_lds = k1_h_table_lds(d.w, d.new_w);
+    int rows = ((kHLds - tab_lds) / row_bytes) & ~(K1_H_RPT - 1);
+    const bool small = tab_lds < kHLds && rows >= K1_H_RPT;
     rows = small ? (rows > 64 ? 64 : rows) : K1_H_RPT;
     std::vector<HWork>& list = small ? c->h_work : p.large;
     for (int r = 0; r < d.h; r += rows) list.push_back(HWork{i, r, (d.h - r) < rows ? (d.h - r) : rows});
-    const int bb = (rows < d.h ? rows : d.h) * row_bytes;
+    const int bb = (rows < d.h ? rows : d.h) * row_bytes + (small ? tab_lds : 0);
     int& cap = small ? p.band_small : p.band_large;
     if (bb > cap) cap = bb;
 }
@@ -345,9 +350,9 @@ int run_h_pass(mme_ctx* c, K1Plan& p, const uint8_t* pix, int n, hipStream_t s, 
 int launch_h_pass(mme_ctx* c, const K1Plan& p, const uint8_t* pix, int n, hipStream_t s, const char* who) {
     if (p.tab_bytes) HIP_TRY(c, launch_resample_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
     const HWork* work = (const HWork*)c->hwork.p;
-    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work, p.n_small, p.band_small, (const uint8_t*)c->htab.p, s));
+    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work, p.n_small, p.band_small, true, (const uint8_t*)c->htab.p, s));
     const int n_large = (int)c->h_work.size() - p.n_small;
-    hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work + p.n_small, n_large, p.band_large,
+    hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work + p.n_small, n_large, p.band_large, false,
                                    (const uint8_t*)c->htab.p, s);
     if (e != hipSuccess) return fail(c, MME_E_HIP, "%s: horizontal pass (%s); band of %d bytes", who, hipGetErrorString(e), p.band_large);
     return MME_OK;
@@ -379,7 +384,7 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     Timed t(c, s, KC_PRE);
     if ((r = launch_h_pass(c, plan, pix, n, s, "mme_preprocess"))) return r;
     HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, any_resize,
-                                        (const uint8_t*)c->htab.p, s));
+                                        (const uint8_t*)c->htab.p, plan.kv_max, s));
     return MME_OK;
 }
 

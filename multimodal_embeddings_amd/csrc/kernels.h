@@ -97,6 +97,12 @@ __host__ __device__ inline int k1_tmp_pitch(int new_w) { return (new_w * 3 + 15)
 //                   group-major so that adjacent output columns read adjacent 16-byte words; zero beyond tap n
 //   height changes: Taps[new_h] | pad to 16 | int vk[new_h][kv]               -- zero beyond tap n
 // gh * 4, kv >= 2 * ceil(scale) + 1 = Resample.c's ksize, the upper bound of n.
+// groups of four taps per output column of the horizontal pass
+__host__ __device__ inline int k1_h_groups(int w, int new_w) { return (2 * ((w + new_w - 1) / new_w) + 1 + 3) >> 2; }
+// bytes of LDS the horizontal table of a crop takes beside its band (table padded to whole 1 KiB DMA sweeps)
+__host__ __device__ inline int k1_h_table_lds(int w, int new_w) {
+    return ((((new_w * 8 + 15) & ~15) + k1_h_groups(w, new_w) * new_w * 16) + 1023) & ~1023;
+}
 struct K1Layout {
     int gh, kv;
     int64_t hk_off, vt_off, vk_off, bytes;
@@ -104,7 +110,7 @@ struct K1Layout {
 __host__ __device__ inline K1Layout k1_layout(int h, int w, int new_h, int new_w) {
     K1Layout L;
     const bool hp = new_w != w, vp = new_h != h;
-    L.gh = hp ? (2 * ((w + new_w - 1) / new_w) + 1 + 3) >> 2 : 0;
+    L.gh = hp ? k1_h_groups(w, new_w) : 0;
     L.kv = vp ? ((2 * ((h + new_h - 1) / new_h) + 1 + 3) & ~3) : 0;
     L.hk_off = hp ? (((int64_t)new_w * 8 + 15) & ~(int64_t)15) : 0;
     L.vt_off = L.hk_off + (int64_t)L.gh * new_w * 16;
@@ -115,9 +121,10 @@ __host__ __device__ inline K1Layout k1_layout(int h, int w, int new_h, int new_w
 constexpr int K1_H_RPT = 4;  // source rows one thread of the horizontal pass filters (bands are whole groups of them)
 // both tap tables of every crop, once per crop (f64 on the device exactly as Resample.c computes them on the host)
 hipError_t launch_resample_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s);
-// horizontal pass over `nwork` bands; band_bytes = the largest band (nrows * w * 3) among them
-hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int band_bytes,
-                           const uint8_t* tab, hipStream_t s);
+// horizontal pass over `nwork` bands; lds_bytes = the largest (table +) band among them; table_in_lds: every band's crop
+// keeps its window + coefficient table in LDS beside the band (k1_h_table_lds)
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int lds_bytes,
+                           bool table_in_lds, const uint8_t* tab, hipStream_t s);
 // multi-tile Mllama output: grid_of int32[n,2] (tiles_h, tiles_w); out f32 [n, max_tiles, 3, T, T]
 hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, const int32_t* grid_of, int n,
                                  const float* lut, float* out, int T, int max_tiles, hipStream_t s);
@@ -125,7 +132,7 @@ hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const C
 hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* boxes, const int64_t* offs, const HWork* work, int nwork,
                              uint8_t* pix, hipStream_t s);
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
-                                    const float* lut /*[3,256]*/, void* patches, bool any_resize, const uint8_t* tab, hipStream_t s);
+                                    const float* lut /*[3,256]*/, void* patches, bool any_resize, const uint8_t* tab, int kv_max, hipStream_t s);
 
 struct PageSimArgs {
     const void* emb;        // bf16 [N, d]

@@ -34,7 +34,6 @@ namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
 constexpr int MAX_TAPS = 160;      // window <= 2*ceil(scale)+1 and scale < 2*MAX_DIM/224
-constexpr int V_KMAX = MAX_TAPS;   // vertical taps per output row kept in LDS (a 1..15-row output of an extreme aspect ratio reaches 2 * 72 + 1)
 
 struct Taps {
     int xmin, n;
@@ -45,18 +44,26 @@ struct __attribute__((packed)) Pix12 {  // 4 RGB pixels at ANY byte address (gfx
 
 // One output coordinate's window and fixed-point weights (Resample.c precompute_coeffs +
 // normalize_coeffs_8bpc, bilinear filter, box = whole image).  store(i, k) receives tap i's coefficient.
-template <class Store>
-__device__ __forceinline__ Taps compute_taps_to(int in_size, int out_size, int xx, Store store) {
+// [xmin, xmax) of one output coordinate (the first lines of precompute_coeffs)
+__device__ __forceinline__ Taps taps_window(int in_size, int out_size, int xx) {
     const double scale = (double)in_size / (double)out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
     const double support = 1.0 * filterscale;
-    const double ss = 1.0 / filterscale;
     const double center = (xx + 0.5) * scale;
     int xmin = (int)(center - support + 0.5);
     if (xmin < 0) xmin = 0;
     int xmax = (int)(center + support + 0.5);
     if (xmax > in_size) xmax = in_size;
-    const int n = xmax - xmin;
+    return Taps{xmin, xmax - xmin};
+}
+template <class Store>
+__device__ __forceinline__ Taps compute_taps_to(int in_size, int out_size, int xx, Store store) {
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double ss = 1.0 / filterscale;
+    const double center = (xx + 0.5) * scale;
+    const Taps win = taps_window(in_size, out_size, xx);
+    const int xmin = win.xmin, n = win.n;
     double ww = 0.0;
     for (int x = 0; x < n; ++x) {
         double t = (x + xmin - center + 0.5) * ss;
@@ -92,9 +99,10 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { 
 // copy loop waits for each load before it stores: one global latency per 4 KiB).  Lanes past the end re-read the last
 // vector into up to 1008 bytes of slack behind the range, which the caller's LDS allocation includes (DMA_SLACK).
 constexpr int DMA_SLACK = 1024;
+template <int NT = 256>
 __device__ __forceinline__ void dma_range_to_lds(const uint4* __restrict__ g, char* lds, int nvec, int tid) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    for (int i = wave * 64; i < nvec; i += 256) glds16(g + min(i + lane, nvec - 1), lds + (size_t)i * 16);
+    for (int i = wave * 64; i < nvec; i += NT) glds16(g + min(i + lane, nvec - 1), lds + (size_t)i * 16);
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -126,8 +134,13 @@ __global__ __launch_bounds__(256) void resample_tables(const CropDesc* __restric
 }
 
 // Horizontal pass.  One workgroup = one band of source rows of one crop (a whole number of K1_H_RPT-row groups except at
-// the crop's end); the band is a single contiguous byte range, fetched with one sweep of 16-byte loads into LDS (all loads
-// in flight at once).  Work item = (row group, output column): lanes of a quad are four neighbouring columns.
+// the crop's end); the band is a single contiguous byte range, fetched by LDS-DMA (all requests in flight at once).
+// Work item = (row group, output column): lanes of a quad are four neighbouring columns.
+// TAB_LDS: the crop's window + coefficient table rides into LDS with the band, so the item loop holds NO vector-memory
+// load: gfx950's vmcnt counts stores too, and with table reads in the loop every item waited for the previous item's
+// stores to complete (one write latency per item).  TAB_LDS = false (very wide crops, whose table does not fit beside
+// four source rows) keeps the table in L1 / L2.
+template <bool TAB_LDS>
 __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
                                                 const CropDesc* __restrict__ crops, const HWork* __restrict__ work,
                                                 const uint8_t* __restrict__ tab) {
@@ -136,9 +149,13 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
     const CropDesc c = crops[wk.crop];
     const int tid = threadIdx.x;
     const int row_bytes = c.w * 3;
-    const Taps* __restrict__ taps = (const Taps*)(tab + c.tab_off);
-    const uint4* __restrict__ hk = (const uint4*)(tab + c.tab_off + (((int64_t)c.new_w * 8 + 15) & ~(int64_t)15));
-    uint8_t* band = (uint8_t*)smem;
+    const int hk_off = (c.new_w * 8 + 15) & ~15;
+    const uint8_t* gtab = tab + c.tab_off;
+    // LDS: [table, padded to whole 1 KiB DMA sweeps] | band (+ slack)
+    const int tab_bytes = TAB_LDS ? hk_off + k1_h_groups(c.w, c.new_w) * c.new_w * 16 : 0;
+    const int tab_pad = (tab_bytes + DMA_SLACK - 1) & ~(DMA_SLACK - 1);
+    if (TAB_LDS) dma_range_to_lds((const uint4*)gtab, smem, tab_bytes >> 4, tid);
+    uint8_t* band = (uint8_t*)smem + tab_pad;
     const uint8_t* src = pix + c.src_off + (int64_t)wk.row0 * row_bytes;
     const int nbytes = wk.nrows * row_bytes;
     const uintptr_t a0 = (uintptr_t)src & ~(uintptr_t)15;
@@ -148,18 +165,12 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
     const int xw = (c.new_w + 3) & ~3;  // columns rounded up to whole quads (the extra lanes repeat the last column)
     const int nrg = (wk.nrows + K1_H_RPT - 1) / K1_H_RPT;
     const int nitems = nrg * xw;
-    // the first item's window and coefficients travel while the band lands
-    int e = tid;
-    int rg = e / xw, xq = e - rg * xw, xx = min(xq, c.new_w - 1);
-    Taps t = e < nitems ? taps[xx] : Taps{0, 0};
-    uint4 k0 = e < nitems ? hk[xx] : uint4{0, 0, 0, 0};
-    dma_wait_all();
-    __syncthreads();
     const uint8_t* bb = band + lead;
     const int pitch = k1_tmp_pitch(c.new_w);
     uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * pitch;
     const int j = tid & 3;  // position in the quad (256 and xw are multiples of 4: quads never straddle items' rows)
-    while (e < nitems) {
+    auto item = [&](int e, Taps t, const uint4* __restrict__ kcol /* this column's coefficient groups, stride new_w */, uint4 k) {
+        const int rg = e / xw, xq = e - rg * xw;
         const int y0 = rg * K1_H_RPT;
         const int ng = (t.n + 3) >> 2;
         const uint8_t* p[K1_H_RPT];
@@ -168,17 +179,8 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
         uint32_t acc[K1_H_RPT][3];
 #pragma unroll
         for (int r = 0; r < K1_H_RPT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1u << (PRECISION_BITS - 1);
-        uint4 k = k0;
-        // next item's window + first coefficient group: independent of this item's arithmetic
-        const int e_n = e + 256;
-        const int rg_n = e_n / xw, xq_n = e_n - rg_n * xw, xx_n = min(xq_n, c.new_w - 1);
-        Taps t_n = Taps{0, 0};
-        if (e_n < nitems) {
-            t_n = taps[xx_n];
-            k0 = hk[xx_n];
-        }
         for (int g = 0; g < ng; ++g) {
-            const uint4 kn = g + 1 < ng ? hk[(int64_t)(g + 1) * c.new_w + xx] : uint4{0, 0, 0, 0};
+            const uint4 kn = g + 1 < ng ? kcol[(int64_t)(g + 1) * c.new_w] : uint4{0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < K1_H_RPT; ++r) {
                 const Pix12 d = *(const Pix12*)(p[r] + g * 12);
@@ -206,11 +208,41 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
             const uint32_t out = j == 0 ? (v | (nb << 24)) : (j == 1 ? ((v >> 8) | (nb << 16)) : ((v >> 16) | (nb << 8)));
             if (j < 3 && y0 + r < wk.nrows && o < c.new_w * 3) *(uint32_t*)(dst + (int64_t)(y0 + r) * pitch + o) = out;
         }
-        e = e_n;
-        rg = rg_n;
-        xq = xq_n;
-        xx = xx_n;
-        t = t_n;
+    };
+    if constexpr (TAB_LDS) {
+        dma_wait_all();
+        __syncthreads();
+        const Taps* taps = (const Taps*)smem;
+        const uint4* hk = (const uint4*)(smem + hk_off);
+        for (int e = tid; e < nitems; e += 256) {
+            const int xx = min(e % xw, c.new_w - 1);
+            item(e, taps[xx], hk + xx, hk[xx]);
+        }
+    } else {
+        const Taps* __restrict__ taps = (const Taps*)gtab;
+        const uint4* __restrict__ hk = (const uint4*)(gtab + hk_off);
+        // the first item's window and coefficients travel while the band lands; later ones one item ahead
+        int e = tid;
+        int xx = min(e % xw, c.new_w - 1);
+        Taps t = e < nitems ? taps[xx] : Taps{0, 0};
+        uint4 k0 = e < nitems ? hk[xx] : uint4{0, 0, 0, 0};
+        dma_wait_all();
+        __syncthreads();
+        while (e < nitems) {
+            const int e_n = e + 256;
+            const int xx_n = min(e_n % xw, c.new_w - 1);
+            Taps t_n = Taps{0, 0};
+            uint4 k_n = uint4{0, 0, 0, 0};
+            if (e_n < nitems) {
+                t_n = taps[xx_n];
+                k_n = hk[xx_n];
+            }
+            item(e, t, hk + xx, k0);
+            e = e_n;
+            xx = xx_n;
+            t = t_n;
+            k0 = k_n;
+        }
     }
 }
 
@@ -218,73 +250,95 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
 //   (a) unchanged 224-wide rows (the synthetic 224 x 224 workload): one contiguous 10752-byte band, 16-byte copies;
 //   (b) the source is the horizontal pass's scratch image (16-byte aligned rows): dword path below;
 //   (c) the width was not resized (rows of the packed crop at any alignment; rare): byte reads straight from global.
-// RESIZE = false: the instantiation for batches of 224 x 224 crops only (form (b) compiled out: half the registers, so the
-// pure stream keeps its occupancy).
+// RESIZE = false: the instantiation for batches of 224 x 224 crops only (form (b) compiled out, 256 threads: the pure
+// stream keeps its occupancy).  RESIZE = true: 512 threads share one canvas band and window, so the LDS-bound three or
+// four workgroups per CU still are 24-32 waves.
+// Dynamic LDS: kk[16][kvs] (this band's coefficient rows; kvs = the batch's largest K1Layout::kv) | window.
 template <bool RESIZE>
-__global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
+__global__ __launch_bounds__(RESIZE ? 512 : 256) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
                                                          const CropDesc* __restrict__ crops, const float* __restrict__ lut,
-                                                         bf16_t* __restrict__ patches, const uint8_t* __restrict__ tab, int window_bytes) {
-    constexpr int ROW = VIT_IMG * 3, ROW4 = ROW / 4, NIT = (VIT_PATCH * ROW4 + 255) / 256;
+                                                         bf16_t* __restrict__ patches, const uint8_t* __restrict__ tab, int window_bytes,
+                                                         int kvs) {
+    constexpr int NT = RESIZE ? 512 : 256;
+    constexpr int ROW = VIT_IMG * 3, ROW4 = ROW / 4, NIT = (VIT_PATCH * ROW4 + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) uint8_t canvas[VIT_PATCH * ROW + 16];
     __shared__ Taps taps[VIT_PATCH];
-    __shared__ int kk[VIT_PATCH * V_KMAX];
     __shared__ float slut[3 * 256];
-    extern __shared__ __attribute__((aligned(16))) uint8_t window[];  // source rows feeding this band (0 bytes for all-224 batches)
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    int* kk = (int*)dyn;
+    uint8_t* window = (uint8_t*)dyn + (size_t)VIT_PATCH * kvs * sizeof(int);  // source rows feeding this band
     const int crop = blockIdx.x / VIT_GRID, py = blockIdx.x - crop * VIT_GRID;
     const CropDesc c = crops[crop];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 768; i += 256) slut[i] = lut[i];
     const bool hpass = c.new_w != c.w;       // Resample.c: horizontal pass only when width changes
     const bool vpass = c.new_h != c.h;
     const int src_row_bytes = c.new_w * 3;   // after the horizontal pass (or unchanged width)
     const int y_first = py * VIT_PATCH, nout = min(y_first + VIT_PATCH, c.new_h) - y_first;  // canvas rows with pixels (may be <= 0)
+    const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
+    const uint8_t* band = src + (int64_t)y_first * src_row_bytes;
+    const bool form_a = !vpass && src_row_bytes == ROW && nout == VIT_PATCH && (((uintptr_t)band) & 15) == 0;
+    const bool form_b = RESIZE && !form_a && hpass && nout > 0 && window_bytes > 0;
+    // form (b): source rows [r0, r1) feed this band -- known from the two window formulas alone, so the first chunk's DMA
+    // starts before the coefficient rows are fetched
+    int r0 = 0, r1 = 0, rows_chunk = 1;
+    const int pitch = k1_tmp_pitch(c.new_w), pitch4 = pitch >> 2;
+    if (form_b) {
+        if (vpass) {
+            const Taps a = taps_window(c.h, c.new_h, y_first), z = taps_window(c.h, c.new_h, y_first + nout - 1);
+            r0 = a.xmin;
+            r1 = z.xmin + z.n;
+        } else {
+            r0 = y_first;
+            r1 = y_first + nout;
+        }
+        rows_chunk = max(window_bytes / pitch, 1);
+        dma_range_to_lds<NT>((const uint4*)(src + (int64_t)r0 * pitch), (char*)window, (min(r0 + rows_chunk, r1) - r0) * (pitch >> 4), tid);
+    }
+    for (int i = tid; i < 768; i += NT) slut[i] = lut[i];
     if (nout > 0) {
         if (vpass) {  // this band's 16 windows and coefficient rows from the crop's table
             const K1Layout L = k1_layout(c.h, c.w, c.new_h, c.new_w);
             const Taps* vt = (const Taps*)(tab + c.tab_off + L.vt_off);
             const int* vk = (const int*)(tab + c.tab_off + L.vk_off);
             if (tid < nout) taps[tid] = vt[y_first + tid];
-            for (int i = tid; i < nout * L.kv; i += 256) {
+            for (int i = tid; i < nout * L.kv; i += NT) {
                 const int ky = i / L.kv, x = i - ky * L.kv;
-                kk[ky * V_KMAX + x] = vk[(int64_t)(y_first + ky) * L.kv + x];
+                kk[ky * kvs + x] = vk[(int64_t)(y_first + ky) * L.kv + x];
             }
         } else {  // no vertical pass: a one-tap "filter" with weight 1.0 copies exactly ((p << 22) + (1 << 21)) >> 22 == p
             if (tid < nout) {
                 taps[tid] = Taps{y_first + tid, 1};
-                kk[tid * V_KMAX] = 1 << PRECISION_BITS;
+                kk[tid * kvs] = 1 << PRECISION_BITS;
             }
         }
     }
+    dma_wait_all();
     __syncthreads();
-    const uint8_t* src = hpass ? tmp + c.tmp_off : pix + c.src_off;
-    const uint8_t* band = src + (int64_t)y_first * src_row_bytes;
-    if (!vpass && src_row_bytes == ROW && nout == VIT_PATCH && (((uintptr_t)band) & 15) == 0) {  // (a); scratch rows of 672 bytes are contiguous too
-        for (int e = tid; e < VIT_PATCH * ROW / 16; e += 256) ((uint4*)canvas)[e] = ((const uint4*)band)[e];
-    } else if (RESIZE && hpass && nout > 0 && window_bytes > 0) {
-        const int pitch = k1_tmp_pitch(c.new_w), pitch4 = pitch >> 2;
+    if (form_a) {  // scratch rows of 672 bytes are contiguous too
+        for (int e = tid; e < VIT_PATCH * ROW / 16; e += NT) ((uint4*)canvas)[e] = ((const uint4*)band)[e];
+    } else if (form_b) {
         const int ncol4 = (src_row_bytes + 3) >> 2;
-        const int r0 = taps[0].xmin, r1 = taps[nout - 1].xmin + taps[nout - 1].n;  // source rows [r0, r1)
-        const int rows_chunk = max(window_bytes / pitch, 1);
         uint32_t acc[NIT][4];
 #pragma unroll
         for (int i = 0; i < NIT; ++i) acc[i][0] = acc[i][1] = acc[i][2] = acc[i][3] = 1u << (PRECISION_BITS - 1);
         const uint32_t* win = (const uint32_t*)window;
         for (int c0 = r0; c0 < r1; c0 += rows_chunk) {
             const int c1 = min(c0 + rows_chunk, r1);
-            if (c0 != r0) __syncthreads();  // every read of the previous chunk is done
-            const uint4* g = (const uint4*)(src + (int64_t)c0 * pitch);
-            dma_range_to_lds(g, (char*)window, (c1 - c0) * (pitch >> 4), tid);
-            dma_wait_all();
-            __syncthreads();
+            if (c0 != r0) {
+                __syncthreads();  // every read of the previous chunk is done
+                dma_range_to_lds<NT>((const uint4*)(src + (int64_t)c0 * pitch), (char*)window, (c1 - c0) * (pitch >> 4), tid);
+                dma_wait_all();
+                __syncthreads();
+            }
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
-                const int e = tid + 256 * i;
+                const int e = tid + NT * i;
                 const int ky = e / ROW4, c4 = e - ky * ROW4;
                 if (ky < nout && c4 < ncol4) {
                     const Taps t = taps[ky];
                     const int lo = max(t.xmin, c0), hi = min(t.xmin + t.n, c1);
                     const uint32_t* wp = win + (lo - c0) * pitch4 + c4;
-                    const int* kp = kk + ky * V_KMAX + (lo - t.xmin);
+                    const int* kp = kk + ky * kvs + (lo - t.xmin);
                     for (int y = 0; y < hi - lo; ++y) {
                         const uint32_t d = wp[y * pitch4];
                         const uint32_t k = (uint32_t)kp[y];
@@ -299,7 +353,7 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
         // canvas: resized pixels, zero outside (pad precedes normalisation)
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            const int e = tid + 256 * i;
+            const int e = tid + NT * i;
             const int ky = e / ROW4, c4 = e - ky * ROW4;
             if (ky < VIT_PATCH) {
                 uint32_t v = 0;
@@ -313,13 +367,13 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
         }
     } else {
         // width not resized: rows of the packed crop (any alignment), bytes straight from global; also the all-padding band
-        for (int e = tid; e < VIT_PATCH * ROW; e += 256) {
+        for (int e = tid; e < VIT_PATCH * ROW; e += NT) {
             const int ky = e / ROW, rem = e - ky * ROW;
             uint8_t v = 0;
             if (ky < nout && rem < src_row_bytes) {
                 const Taps t = taps[ky];
-                const int* k = kk + ky * V_KMAX;
-                const int64_t spitch = hpass ? k1_tmp_pitch(c.new_w) : src_row_bytes;
+                const int* k = kk + ky * kvs;
+                const int64_t spitch = hpass ? pitch : src_row_bytes;
                 const uint8_t* p = src + (int64_t)t.xmin * spitch + rem;
                 uint32_t ss0 = 1u << (PRECISION_BITS - 1);
                 for (int y = 0; y < t.n; ++y) ss0 = mad24(p[(int64_t)y * spitch], (uint32_t)k[y], ss0);
@@ -331,7 +385,7 @@ __global__ __launch_bounds__(256) void resize_v_patchify(const uint8_t* __restri
     __syncthreads();
     // 14 patches x 768 values; a thread emits 8 consecutive kx of one (patch, c, ky)
     bf16_t* out = patches + ((int64_t)crop * VIT_NP + py * VIT_GRID) * VIT_D;
-    for (int e = tid; e < VIT_GRID * VIT_D / 8; e += 256) {
+    for (int e = tid; e < VIT_GRID * VIT_D / 8; e += NT) {
         const int px = e / (VIT_D / 8), q = e - px * (VIT_D / 8);
         const int ch = q >> 5, ky = (q >> 1) & 15, kx0 = (q & 1) * 8;
         const uint8_t* cp = canvas + ky * ROW + (px * VIT_PATCH + kx0) * 3 + ch;
@@ -445,27 +499,38 @@ hipError_t launch_resample_tables(const CropDesc* crops, int n, uint8_t* tab, hi
     return hipGetLastError();
 }
 
-hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int band_bytes,
-                           const uint8_t* tab, hipStream_t s) {
+hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int lds_bytes,
+                           bool table_in_lds, const uint8_t* tab, hipStream_t s) {
     if (nwork <= 0) return hipSuccess;
-    // one band + alignment lead (<= 15) + vector rounding (<= 15) + the last tap group's over-read (<= 9 bytes, zero weights)
-    const size_t smem = (size_t)band_bytes + 64 + DMA_SLACK;
+    // lds_bytes = (padded table +) one band; + alignment lead (<= 15) + vector rounding (<= 15) + the last tap group's
+    // over-read (<= 9 bytes, zero weights) + the DMA sweep's slack
+    const size_t smem = (size_t)lds_bytes + 64 + DMA_SLACK;
     if (smem > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = ensure_dynamic_lds((const void*)resize_h, (int)smem); e != hipSuccess) return e;
-    hipLaunchKernelGGL(resize_h, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
+    const void* fn = table_in_lds ? (const void*)resize_h<true> : (const void*)resize_h<false>;
+    if (hipError_t e = ensure_dynamic_lds(fn, (int)smem); e != hipSuccess) return e;
+    if (table_in_lds)
+        hipLaunchKernelGGL(resize_h<true>, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
+    else
+        hipLaunchKernelGGL(resize_h<false>, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
     return hipGetLastError();
 }
 
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n, const float* lut,
-                                    void* patches, bool any_resize, const uint8_t* tab, hipStream_t s) {
+                                    void* patches, bool any_resize, const uint8_t* tab, int kv_max, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     // the LDS window is only needed when some crop is resized or partially fills the canvas; the
     // all-224x224 batch keeps the small footprint (more workgroups per CU for a pure stream)
     static const int win_kb = getenv("MME_K1_VWIN") ? atoi(getenv("MME_K1_VWIN")) : 16;  // tuning switch (KiB per chunk)
-    const int window = any_resize ? (win_kb < 1 ? 1 : (win_kb > 96 ? 96 : win_kb)) * 1024 : 0;
-    if (any_resize)
-        hipLaunchKernelGGL(resize_v_patchify<true>, dim3(n * VIT_GRID), dim3(256), window + DMA_SLACK, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, window);
-    else
-        hipLaunchKernelGGL(resize_v_patchify<false>, dim3(n * VIT_GRID), dim3(256), 0, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, 0);
+    const int kvs = kv_max < 4 ? 4 : ((kv_max + 3) & ~3);
+    if (kvs > MAX_TAPS) return hipErrorInvalidValue;
+    const int kk_bytes = VIT_PATCH * kvs * (int)sizeof(int);
+    if (any_resize) {
+        const int window = (win_kb < 1 ? 1 : (win_kb > 96 ? 96 : win_kb)) * 1024;
+        const int smem = kk_bytes + window + DMA_SLACK;
+        if (hipError_t e = ensure_dynamic_lds((const void*)resize_v_patchify<true>, smem); e != hipSuccess) return e;
+        hipLaunchKernelGGL(resize_v_patchify<true>, dim3(n * VIT_GRID), dim3(512), smem, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, window, kvs);
+    } else {
+        hipLaunchKernelGGL(resize_v_patchify<false>, dim3(n * VIT_GRID), dim3(256), kk_bytes, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, 0, kvs);
+    }
     return hipGetLastError();
 }
