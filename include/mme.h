@@ -115,6 +115,20 @@ int mme_set_ln_fusion(mme_ctx* ctx, int mode);
 int mme_crop_boxes(mme_ctx* ctx, const uint8_t* page_dev, int H, int W, const int32_t* boxes_host, int n, uint8_t* pix_dev,
                    const int64_t* offs_host, void* stream);
 
+/* ---- K13: merge the detector's grid passes -- class-aware non-maximum suppression ----------
+ * Replaces apply_non_max_suppression / calculate_iou (3_combine_grids.py:44-137), the O(n^2) list.index / list.pop loop
+ * that turns the boxes of all grid passes of a page into the page's region list: keep the highest-scoring box left (the
+ * first of equal scores), drop every remaining box of the same class whose IoU with it exceeds iou_threshold.  Many pages
+ * per call, one workgroup each; float64 in the reference's operation order, so the kept set and its order are identical.
+ * All pointers are HOST memory (the boxes come from JSON and the result goes back into JSON); the call returns when
+ * the results are there.
+ *   boxes f64[n,4] (x0,y0,x1,y1), scores f64[n], classes int32[n]; page p owns rows [page_offs[p], page_offs[p+1]),
+ *   page_offs int32[pages+1] with page_offs[0] = 0, at most 32768 boxes per page
+ *   keep int32[n]: for page p, keep[page_offs[p] + k] = page-local index of the k-th kept box in the reference's output
+ *   order, -1 beyond keep_count[p]; keep_count int32[pages] */
+int mme_nms_boxes(mme_ctx* ctx, const double* boxes, const double* scores, const int32_t* classes, const int32_t* page_offs, int pages,
+                  double iou_threshold, int32_t* keep, int32_t* keep_count, void* stream);
+
 /* ---- K1: crop -> resize -> pad -> normalise -> patchify ------------------------------
  * Replaces, per crop, `processor(images=[image])` (embedder.py:117-121; transformers
  * image_processing_pil_mllama.py:483-541 with tile 224, one tile): aspect-preserving

@@ -81,6 +81,7 @@ EXPORTS = {
     "mme_preprocess_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "mme_crop_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mme_nms_boxes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_neighbours": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_set_neighbour_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -305,6 +306,23 @@ class Engine:
         self._check(self.lib.mme_crop_boxes(self.h, page.data_ptr(), int(page.shape[0]), int(page.shape[1]), b.ctypes.data, n,
                                             pix.data_ptr(), offs.ctypes.data, self._stream()), "mme_crop_boxes")
         return pix, offs, hw
+
+    def nms_boxes(self, boxes, scores, classes, page_offs, iou_threshold=0.5):
+        """K13 (3_combine_grids.py:80-137) over many pages: host arrays in, list of kept page-local index arrays out
+        (the reference's output order)."""
+        boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.float64).reshape(-1, 4))
+        scores = np.ascontiguousarray(scores, dtype=np.float64).reshape(-1)
+        classes = np.ascontiguousarray(classes, dtype=np.int32).reshape(-1)
+        page_offs = np.ascontiguousarray(page_offs, dtype=np.int32).reshape(-1)
+        pages = len(page_offs) - 1
+        n = len(scores)
+        if pages < 0 or len(boxes) != n or len(classes) != n or (pages >= 0 and int(page_offs[-1]) != n):
+            raise MmeError("nms_boxes: boxes / scores / classes / page_offs disagree")
+        keep = np.full(n, -1, dtype=np.int32)
+        count = np.zeros(max(pages, 0), dtype=np.int32)
+        self._check(self.lib.mme_nms_boxes(self.h, boxes.ctypes.data, scores.ctypes.data, classes.ctypes.data, page_offs.ctypes.data,
+                                           pages, float(iou_threshold), keep.ctypes.data, count.ctypes.data, self._stream()), "mme_nms_boxes")
+        return [keep[page_offs[p] : page_offs[p] + count[p]].copy() for p in range(pages)]
 
     def preprocess(self, pix, offs, hw):
         """pix: uint8 CUDA tensor (concatenated HWC crops, >=16 spare bytes at the end)."""

@@ -18,7 +18,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libmme.so")
-SOURCES = ["gemm.hip", "gemm256r.hip", "rowops.hip", "attention.hip", "preprocess.hip", "page_reduce.hip", "cluster.hip", "neighbours.hip", "launch_state.hip", "comm.hip", "attention_tiles.hip", "tilevit.hip", "capi.hip", "capi_tilevit.hip"]
+SOURCES = ["gemm.hip", "gemm256r.hip", "rowops.hip", "attention.hip", "preprocess.hip", "page_reduce.hip", "cluster.hip", "neighbours.hip", "launch_state.hip", "comm.hip", "nms.hip", "attention_tiles.hip", "tilevit.hip", "capi.hip", "capi_tilevit.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "ctx.h", os.path.join("..", "..", "include", "mme.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

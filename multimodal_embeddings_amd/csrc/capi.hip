@@ -851,6 +851,45 @@ int mme_crop_boxes(mme_ctx* c, const uint8_t* page, int H, int W, const int32_t*
     return MME_OK;
 }
 
+int mme_nms_boxes(mme_ctx* c, const double* boxes, const double* scores, const int32_t* classes, const int32_t* page_offs, int pages,
+                  double iou_threshold, int32_t* keep, int32_t* keep_count, void* stream) {
+    if (!c) return MME_E_ARG;
+    if (pages < 0) return fail(c, MME_E_ARG, "mme_nms_boxes: pages = %d", pages);
+    if (pages == 0) return MME_OK;
+    if (!page_offs || !keep_count) return fail(c, MME_E_ARG, "mme_nms_boxes: null pointer");
+    if (page_offs[0] != 0) return fail(c, MME_E_ARG, "mme_nms_boxes: page_offs[0] must be 0");
+    for (int p = 0; p < pages; ++p) {
+        const int64_t k = (int64_t)page_offs[p + 1] - page_offs[p];
+        if (k < 0 || k > 32768) return fail(c, MME_E_ARG, "mme_nms_boxes: page %d has %lld boxes; supported 0..32768 per page", p, (long long)k);
+    }
+    const size_t n = (size_t)page_offs[pages];
+    if (n && (!boxes || !scores || !classes || !keep)) return fail(c, MME_E_ARG, "mme_nms_boxes: null pointer");
+    if (!(iou_threshold == iou_threshold)) return fail(c, MME_E_ARG, "mme_nms_boxes: iou_threshold is NaN");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // one staging block: boxes | scores | classes | order | keep | page_offs | keep_count
+    const size_t o_sc = n * 32, o_cl = o_sc + n * 8, o_or = o_cl + n * 4, o_kp = o_or + n * 4, o_po = (o_kp + n * 4 + 15) & ~(size_t)15;
+    const size_t o_kc = o_po + ((size_t)(pages + 1) * 4 + 15) / 16 * 16, total = o_kc + (size_t)pages * 4 + 16;
+    int r;
+    if ((r = ensure(c, c->hwork, total))) return r;
+    char* d = (char*)c->hwork.p;
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(d, boxes, n * 32, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_sc, scores, n * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(d + o_cl, classes, n * 4, hipMemcpyHostToDevice, s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(d + o_po, page_offs, (size_t)(pages + 1) * 4, hipMemcpyHostToDevice, s));
+    {
+        Timed t(c, s, KC_PRE);
+        HIP_TRY(c, launch_nms_pages((const double*)d, (const double*)(d + o_sc), (const int32_t*)(d + o_cl), (const int32_t*)(d + o_po), pages,
+                                    iou_threshold, (int32_t*)(d + o_or), (int32_t*)(d + o_kp), (int32_t*)(d + o_kc), s));
+    }
+    if (n) HIP_TRY(c, hipMemcpyAsync(keep, d + o_kp, n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(keep_count, d + o_kc, (size_t)pages * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));  // results are host data (the JSON of the next step is built from them)
+    return MME_OK;
+}
+
 int mme_neighbours(mme_ctx* c, const uint16_t* emb, int N, int d, const int32_t* group, int row0, int nrows, int fetch, int top_n,
                    int keep_self, float min_sim, float max_sim, int32_t* idx, float* sim, void* stream) {
     if (!c) return MME_E_ARG;

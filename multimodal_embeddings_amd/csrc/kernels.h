@@ -134,6 +134,12 @@ hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* b
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
                                     const float* lut /*[3,256]*/, void* patches, bool any_resize, const uint8_t* tab, int kv_max, hipStream_t s);
 
+// K13: class-aware greedy NMS, one workgroup per page (3_combine_grids.py:80-137).  boxes f64[n,4] (x0,y0,x1,y1),
+// page p owns boxes [page_offs[p], page_offs[p+1]); order int32[n] is scratch; keep int32[n] receives, per page, the
+// page-local indices of the kept boxes in the reference's output order (-1 beyond keep_count[p]).  <= 32768 boxes per page.
+hipError_t launch_nms_pages(const double* boxes, const double* scores, const int32_t* classes, const int32_t* page_offs, int pages,
+                            double thr, int32_t* order, int32_t* keep, int32_t* keep_count, hipStream_t s);
+
 struct PageSimArgs {
     const void* emb;        // bf16 [N, d]
     int64_t N;

@@ -27,6 +27,8 @@ Fixtures written
   tile_vit_cases.npz     transformers MllamaVisionModel (560 / 14 / 1280-d / 32 + 8 layers, seeded weights) rows per tile grid
                          (run separately: `make_golden.py --only-tile-vit`, ~15 min of CPU)
   query_cases.json       a brute-force store queried through the REAL safe_query (wrc:73-95): ids / distances
+  nms_cases.json         boxes of the bundled pages (3_combined_bboxes/json, data files) and seeded box sets through the REAL
+                         apply_non_max_suppression (3_combine_grids.py:80-137): kept indices in output order
 """
 from __future__ import annotations
 
@@ -466,6 +468,65 @@ def golden_tile_vit():
     print("tile-ViT golden written:", sorted(first))
 
 
+def golden_nms():
+    """The REAL apply_non_max_suppression (3_combine_grids.py:80-137) on the bundled pages' combined boxes at several
+    thresholds and on seeded box sets (ties, duplicates, touching and degenerate boxes): kept indices in output order.
+    The function returns boxes, not indices; the inner box lists keep their identity through its shallow copies."""
+    import importlib.util
+
+    for n in ["cv2"]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    spec = importlib.util.spec_from_file_location("ref_combine_grids", os.path.join(REF, "3_combine_grids.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+
+    def run(boxes, scores, classes, thr):
+        boxes = [list(map(float, b)) for b in boxes]
+        ident = {id(b): i for i, b in enumerate(boxes)}
+        names = [f"class{c}" for c in classes]
+        fb, fs, fc, fn = mod.apply_non_max_suppression(boxes, list(scores), list(classes), names, thr)
+        keep = [ident[id(b)] for b in fb]
+        assert [scores[i] for i in keep] == fs and [classes[i] for i in keep] == fc and [names[i] for i in keep] == fn
+        return keep
+
+    cases = []
+    pages = sorted(glob.glob(os.path.join(REF, "3_combined_bboxes", "json", "*_combined.json")))
+    for path in pages:
+        d = json.load(open(path))
+        case = {"name": os.path.basename(path)[:40], "boxes": d["boxes"], "scores": d["scores"], "classes": d["classes"], "runs": []}
+        for thr in (0.5, 0.3, 0.1, 0.0):
+            case["runs"].append({"iou_threshold": thr, "keep": run(d["boxes"], d["scores"], d["classes"], thr)})
+        # the bundled files ARE the reference's output at 0.5: suppression must be idempotent on them
+        assert case["runs"][0]["keep"] == sorted(range(len(d["scores"])), key=lambda i: -d["scores"][i]), path
+        cases.append(case)
+    rng = np.random.default_rng(31)
+    for n, kind in [(1, "one"), (2, "pair"), (7, "few"), (64, "int"), (300, "mixed"), (1200, "dense"), (257, "ties")]:
+        centres = rng.uniform(0, 2000, (max(n // 6, 1), 2))
+        c = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 12, (n, 2))
+        wh = rng.uniform(20, 400, (n, 2))
+        boxes = np.concatenate([c - wh / 2, c + wh / 2], axis=1)
+        if kind in ("int", "ties"):
+            boxes = np.round(boxes)  # whole-pixel boxes: exact touching edges and equal IoUs
+        scores = rng.uniform(0.2, 1.0, n)
+        if kind in ("ties", "int"):
+            scores = np.round(scores, 1)  # many equal scores: the first in list order wins
+        classes = rng.integers(0, 4 if kind != "dense" else 10, n)
+        if n >= 7:
+            boxes[3] = boxes[1]                                   # exact duplicate
+            classes[3] = classes[1]
+            boxes[5] = [boxes[4][2], boxes[4][1], boxes[4][2] + 50, boxes[4][3]]  # shares an edge with box 4 (area branch, IoU 0)
+            classes[5] = classes[4]
+            boxes[6] = [100.0, 100.0, 100.0, 300.0]               # zero width
+        boxes, scores, classes = boxes.tolist(), scores.tolist(), [int(v) for v in classes]
+        case = {"name": f"seeded {kind} n={n}", "boxes": boxes, "scores": scores, "classes": classes, "runs": []}
+        for thr in (0.5, 0.25, 0.0):
+            case["runs"].append({"iou_threshold": thr, "keep": run(boxes, scores, classes, thr)})
+        cases.append(case)
+    cases.append({"name": "empty", "boxes": [], "scores": [], "classes": [], "runs": [{"iou_threshold": 0.5, "keep": []}]})
+    json.dump({"cases": cases}, open(os.path.join(HERE, "nms_cases.json"), "w"))
+    print("nms:", len(cases), "cases,", sum(len(c["scores"]) for c in cases), "boxes")
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix="golden_")
     os.chdir(scratch)
@@ -473,6 +534,10 @@ def main():
     w, ref_embedder = import_reference()
     if "--only-tile-vit" in sys.argv:
         golden_tile_vit()
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+    if "--only-nms" in sys.argv:
+        golden_nms()
         shutil.rmtree(scratch, ignore_errors=True)
         return
     if "--only-query" in sys.argv:

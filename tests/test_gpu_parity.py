@@ -82,7 +82,9 @@ def test_preprocess_bit_exact_synthetic_shapes(engine):
 
     rng = np.random.default_rng(11)
     shapes = [(224, 224), (20, 63), (63, 20), (1, 1), (1, 300), (300, 1), (5114, 60), (37, 3862), (223, 225), (225, 223),
-              (448, 448), (100, 100), (1000, 333), (224, 100), (100, 224), (17, 8000), (8000, 9), (2000, 1999), (16, 16), (500, 224)]
+              (448, 448), (100, 100), (1000, 333), (224, 100), (100, 224), (17, 8000), (8000, 9), (2000, 1999), (16, 16), (500, 224),
+              # one to three output rows / columns of an extreme aspect ratio: up to 2 * 72 + 1 taps per output coordinate
+              (71, 8000), (106, 8000), (140, 8000), (8000, 106), (8000, 140), (1400, 1350), (1351, 700), (3000, 2049)]
     arrays = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
     pix, offs, hw = _pack(arrays)
     patches = engine.preprocess(pix, offs, hw)

@@ -287,6 +287,22 @@ def test_region_rows_and_crops_match_reference_region_processor(golden_dir):
         assert list(crop.shape) == shape and hashlib.sha256(crop.tobytes()).hexdigest() == sha
 
 
+def test_nms_oracle_keeps_what_the_reference_function_kept(golden_dir):
+    """oracle.regions.nms_keep == the indices the REAL apply_non_max_suppression (3_combine_grids.py:80-137) kept, in its
+    output order: the boxes of the 19 bundled pages at four thresholds (idempotent at the 0.5 they were produced with) and
+    seeded box sets with equal scores, duplicates, boxes sharing an edge and zero-width boxes."""
+    from oracle import regions as oreg
+
+    cases = json.load(open(os.path.join(golden_dir, "nms_cases.json")))["cases"]
+    assert len(cases) >= 27 and sum(len(c["scores"]) for c in cases) > 5000
+    for c in cases:
+        for run in c["runs"]:
+            assert oreg.nms_keep(c["boxes"], c["scores"], c["classes"], run["iou_threshold"]) == run["keep"], (c["name"], run["iou_threshold"])
+    # calculate_iou's branches: disjoint -> 0, shared edge -> 0 through the area branch, zero-area pair -> 0, identical -> 1
+    assert oreg.box_iou([0, 0, 10, 10], [[20, 0, 30, 10], [10, 0, 20, 10], [0, 0, 10, 10], [0, 0, 5, 10]]).tolist() == [0.0, 0.0, 1.0, 0.5]
+    assert oreg.box_iou([1, 1, 1, 1], [[1, 1, 1, 1]]).tolist() == [0.0]
+
+
 def test_tile_preprocessing_matches_transformers_mllama_processor(golden_dir):
     """oracle.preprocess_tiles == transformers' MllamaImageProcessorPil at the checkpoint geometry (tile 560,
     <= 4 tiles): canvas choice, aspect-ratio id / mask, tile count, and every f32 pixel value (sha256) on the
