@@ -10,7 +10,7 @@
 // fragments stay in registers -- and walks the keys in tiles of 128 with an online softmax (running maximum and sum per
 // query, both in-lane: S^T = K . Q^T puts the query on the lane and the keys in the accumulator registers, and the
 // exponentiated tile is already the B operand of O^T = V^T . P^T, as in attention.hip).  K and V tiles are staged
-// through registers into two LDS buffers (global loads of tile t+2 are in flight while tile t is computed; the row
+// through registers into a ring of three LDS buffers (global loads of tile t+2 are in flight while tile t is computed; the row
 // pitches -- K 176 B, V 192 B -- make the b128 fragment reads and the transposed b64 reads conflict-free; V is padded
 // to 96 head dims with zeros so that the third 32-row block of O^T is a whole MFMA).
 #include <type_traits>
@@ -26,23 +26,32 @@ constexpr int TV_LD = 3 * TV_D * 2;                                             
 constexpr int KT = 128;                                                                // keys per tile
 constexpr int KROW = 176, VROW = 192;                                                  // LDS row pitches
 constexpr int BUFB = KT * (KROW + VROW);                                               // 47 104 B per buffer
+constexpr int NBUF = 3;                                                                // key/value tiles resident in LDS
 constexpr int QB = 256;                                                                // queries per workgroup
 constexpr int NQB = (TV_T + QB - 1) / QB;                                              // 26
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
-
-#define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
 __device__ __forceinline__ bool tv_is_pad(int tok_index, int ntile) {
     const int tile = tok_index / TV_TOKP, tok = tok_index - tile * TV_TOKP;
     return tok >= TV_TOK || tile >= ntile;
 }
 
+// Schedule (round 2, second cut).  The online softmax works on GRANULES of 64 keys (two per staged tile); every wave
+// runs the same pieces per granule -- S^T (10 MFMAs), the running maximum + rescale (vector ALU), exponentials +
+// O^T += V^T P^T (12 MFMAs beside ~130 vector instructions) -- and ONE barrier per 128-key tile hands the next staged
+// tile over.  With all eight waves in the same order the two waves of a SIMD did matrix work at the same time and
+// vector work at the same time (6.7 k cycles per tile = the SUM of the 2.8 k of MFMA issue and the ~4 k of vector issue
+// of the pair).  Now waves 4-7 run HALF A GRANULE BEHIND waves 0-3: they end an interval with the scores + maximum of
+// the tile's second granule and begin the next one with its exponentials + P.V (32 score registers carried across the
+// barrier), so on every SIMD one wave's exponentials sit beside the other's MFMAs throughout (guide: stagger by wave
+// >= 4, not by parity).  V of tile t-1 is still read during interval t, so the ring holds THREE tiles (141 KiB).
 __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          const int32_t* __restrict__ ntiles) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];  // 2 x (K[128][176 B] | V[128][192 B])
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // NBUF x (K[128][176 B] | V[128][192 B])
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;  // 0: a tile's three pieces inside one interval; 1: half a tile behind
     const int qb = blockIdx.x % NQB, head = (blockIdx.x / NQB) % TV_H, img = blockIdx.x / (NQB * TV_H);
     const int ntile = ntiles[img];
     const char* base = (const char*)qkv + (size_t)img * TV_T * TV_LD + head * (TV_DH * 2);
@@ -52,8 +61,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
     const bool q_pad = q >= TV_T || tv_is_pad(q, ntile);
     const bool wave_has_pad_query = __ballot(q_pad) != 0;
 
-    // V columns 80..95 of every row, both buffers: zero once (never overwritten)
-    for (int i = tid; i < 2 * KT * 2; i += 512) {
+    // V columns 80..95 of every row, all buffers: zero once (never overwritten)
+    for (int i = tid; i < NBUF * KT * 2; i += 512) {
         const int buf = i / (KT * 2), row = (i >> 1) % KT, c = i & 1;
         *(uint4*)(lds + buf * BUFB + KT * KROW + row * VROW + 160 + c * 16) = make_uint4(0, 0, 0, 0);
     }
@@ -66,19 +75,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
         for (int ks = 0; ks < 5; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 32);
     }
 
-    // staging: 2560 16-byte chunks per tile (K: 128 rows x 10, then V), five per thread, in five NAMED registers
-    // (an array captured by a lambda lands in scratch memory)
+    // staging: 2560 16-byte chunks per tile (128 rows x (10 of K + 10 of V)); four threads share a row and take chunks
+    // q4, q4 + 4, ... q4 + 16 of its 20, so one row offset per thread addresses all five (five NAMED registers: an array
+    // captured by a lambda lands in scratch memory)
     uint4 stage0, stage1, stage2, stage3, stage4;
-    int g_off[5], l_off[5];  // per-chunk global offset (without the key tile) and LDS offset: loop invariants
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int c = tid + 512 * i, isv = c >= 1280, cc = isv ? c - 1280 : c;
-        const int row = cc / 10, ch = cc - row * 10;
-        g_off[i] = row * TV_LD + (isv ? 2 : 1) * (TV_D * 2) + ch * 16;
-        l_off[i] = (isv ? KT * KROW + row * VROW : row * KROW) + ch * 16;
-    }
+    const int srow = tid >> 2, q4 = tid & 3;
+    // chunk j of a row: K bytes [16 j, 16 j + 16) for j < 10, V bytes [16 (j - 10), ...) else
+    auto g_chunk = [&](int i) { const int j = q4 + 4 * i; return (j < 10 ? TV_D * 2 + j * 16 : 2 * TV_D * 2 + (j - 10) * 16); };
+    auto l_chunk = [&](int i) { const int j = q4 + 4 * i; return (j < 10 ? srow * KROW + j * 16 : KT * KROW + srow * VROW + (j - 10) * 16); };
     // rows past the end of the sequence (last tile) re-read the last row: finite data, masked later
-#define TV_LOAD(i, t) *(const uint4*)(base + (size_t)(t) * KT * TV_LD + min(g_off[i], (TV_T - 1 - (t) * KT) * TV_LD + g_off[i] % TV_LD))
+#define TV_LOAD(i, t) *(const uint4*)(base + (size_t)min((t) * KT + srow, TV_T - 1) * TV_LD + g_chunk(i))
 #define LOAD_TILE(t)                \
     stage0 = TV_LOAD(0, t);         \
     stage1 = TV_LOAD(1, t);         \
@@ -86,11 +92,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
     stage3 = TV_LOAD(3, t);         \
     stage4 = TV_LOAD(4, t);
 #define STORE_TILE(buf)                                  \
-    *(uint4*)(lds + (buf) * BUFB + l_off[0]) = stage0;   \
-    *(uint4*)(lds + (buf) * BUFB + l_off[1]) = stage1;   \
-    *(uint4*)(lds + (buf) * BUFB + l_off[2]) = stage2;   \
-    *(uint4*)(lds + (buf) * BUFB + l_off[3]) = stage3;   \
-    *(uint4*)(lds + (buf) * BUFB + l_off[4]) = stage4;
+    *(uint4*)(lds + (buf) * BUFB + l_chunk(0)) = stage0;   \
+    *(uint4*)(lds + (buf) * BUFB + l_chunk(1)) = stage1;   \
+    *(uint4*)(lds + (buf) * BUFB + l_chunk(2)) = stage2;   \
+    *(uint4*)(lds + (buf) * BUFB + l_chunk(3)) = stage3;   \
+    *(uint4*)(lds + (buf) * BUFB + l_chunk(4)) = stage4;
 
     constexpr int NT = (TV_T + KT - 1) / KT;  // 51 key tiles (the last holds 32 keys)
     LOAD_TILE(0)
@@ -110,103 +116,140 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
     const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     const int v_lane_off = (4 * (g >> 1) + tq) * VROW + (16 * (g & 1) + 4 * tp) * 2;
 
-    for (int t = 0; t < NT; ++t) {
-        const int buf = t & 1;
-        const char* Kl = lds + buf * BUFB;
-        const char* Vl = Kl + KT * KROW;
-        if (t > 0) __syncthreads();  // tile t is in LDS (written one iteration ago); everybody left tile t-1
-        if (t + 1 < NT) {
-            STORE_TILE(buf ^ 1)
-        }
-        if (t + 2 < NT) {
-            LOAD_TILE(t + 2)
-        }
-        if (!wave_active) continue;
+    // state of the 64-key granule whose exponentials + P.V are still to come (waves 4-7 carry it across the barrier)
+    f32x16 s[2];          // s[u][e] = score of key 128 t + 64 half + 32u + (e&3) + 8(e>>2) + 4hh
+    float mref = 0.f;     // reference point of the exponentials
+    unsigned msk = 0;     // bit 16 u + e: score s[u][e] does not count
+    bool masked = false;  // wave-uniform: this granule can hold a score that does not count
 
-        // ---- S^T for the four 32-key sub-tiles: s[u][e] = score of key t*128 + 32u + (e&3) + 8(e>>2) + 4hh
-        f32x16 s[4];
+    // ---- S^T for the two 32-key sub-tiles of a granule
+    auto scores = [&](const char* Kl, int half) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
             f32x16 a;
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 5; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(Kl + (u * 32 + r) * KROW + (2 * ks + hh) * 16);
+                const bf16x8 kf = *(const bf16x8*)(Kl + (half * 64 + u * 32 + r) * KROW + (2 * ks + hh) * 16);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], a, 0, 0, 0);
             }
             s[u] = a;
         }
-        // keys past the sequence end (last tile) never count; (padding query, padding key) pairs are masked.  The mask is a
-        // per-lane bit set consulted where a score is USED (maximum, exponential) -- the score registers themselves, fresh
-        // MFMA results, are left alone -- and only tiles that can contain a masked pair take that form of the body.
-        const int k0 = t * KT;
-        const bool tail = k0 + KT > TV_T;
-        const int tok0 = k0 % TV_TOKP;
-        const bool tile_has_pad_key = tok0 + KT > TV_TOK || (k0 + KT - 1) / TV_TOKP >= ntile;  // wave-uniform
-        auto softmax_pv = [&](auto masked_tag) {
-            constexpr bool MASKED = decltype(masked_tag)::value;
-            unsigned long long msk = 0;  // bit 16 u + e: score s[u][e] does not count
-            if constexpr (MASKED) {
+    };
+    // ---- running maximum + rescale.  Keys past the sequence end (last tile) never count; (padding query, padding key)
+    // pairs are masked.  The mask is a per-lane bit set consulted where a score is USED (maximum, exponential) -- the
+    // score registers themselves, fresh MFMA results, are left alone -- and only granules that can contain a masked pair
+    // take that form of the body.
+    auto maximum = [&](int k0, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        msk = 0;
+        if constexpr (MASKED) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = k0 + 32 * u + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        if (key >= TV_T || (q_pad && tv_is_pad(key, ntile))) msk |= 1ull << (16 * u + e);
-                    }
-            }
-            auto dead = [&](int u, int e) { return MASKED && ((msk >> (16 * u + e)) & 1ull) != 0; };
-            // ---- online softmax
-            float mx = m_run;
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + 32 * u + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (key >= TV_T || (q_pad && tv_is_pad(key, ntile))) msk |= 1u << (16 * u + e);
+                }
+        }
+        // max over the raw scores, scaled once: fl(s * sc) is monotone in s (sc > 0), so this is max_i fl(s_i * sc)
+        float raw = -INFINITY;
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, dead(u, e) ? -INFINITY : s[u][e] * sc);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // a query whose keys are all masked so far keeps mx = -inf: use 0 as the reference point (all p = 0)
-            const float mref = mx == -INFINITY ? 0.f : mx;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - mref);  // 0 when m_run = -inf
-            m_run = mx;
+            for (int e = 0; e < 16; ++e) raw = fmaxf(raw, (MASKED && ((msk >> (16 * u + e)) & 1u)) ? -INFINITY : s[u][e]);
+        float mx = fmaxf(m_run, raw * sc);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // a query whose keys are all masked so far keeps mx = -inf: use 0 as the reference point (all p = 0)
+        mref = mx == -INFINITY ? 0.f : mx;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mref);  // 0 when m_run = -inf
+        m_run = mx;
+        if (__ballot(alpha != 1.0f) != 0) {  // wave-uniform; a multiplication by 1.0f is exact, so skipping it changes nothing
             l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < 3; ++db)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
-            // ---- P = exp2(s*sc - m), row sums, O^T += V^T . P^T in 8 steps of 16 keys
-            float psum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                bf16x8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float pv = __builtin_amdgcn_exp2f(fmaf(s[i >> 1][8 * (i & 1) + j], sc, -mref));
-                    if (dead(i >> 1, 8 * (i & 1) + j)) pv = 0.f;
-                    psum += pv;
-                    pf[j] = (bf16_t)pv;
-                }
-#pragma unroll
-                for (int db = 0; db < 3; ++db) {
-                    const char* va = Vl + i * 16 * VROW + v_lane_off + db * 64;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * VROW));
-                    const s16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[db], 0, 0, 0);
-                }
-            }
-            l_run += psum;
-        };
-        if (tail || (wave_has_pad_query && tile_has_pad_key)) {
-            softmax_pv(std::true_type{});
-        } else {
-            softmax_pv(std::false_type{});
         }
-    }
+    };
+    // ---- P = exp2(s*sc - m), row sums, O^T += V^T . P^T in 4 steps of 16 keys
+    auto exp_pv = [&](const char* Vl, int half, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float pv = __builtin_amdgcn_exp2f(fmaf(s[i >> 1][8 * (i & 1) + j], sc, -mref));
+                if (MASKED && ((msk >> (16 * (i >> 1) + 8 * (i & 1) + j)) & 1u)) pv = 0.f;
+                psum += pv;
+                pf[j] = (bf16_t)pv;
+            }
+#pragma unroll
+            for (int db = 0; db < 3; ++db) {
+                const char* va = Vl + (half * 4 + i) * 16 * VROW + v_lane_off + db * 64;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * VROW));
+                const s16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[db], 0, 0, 0);
+            }
+        }
+        l_run += psum;
+    };
+    auto granule_masked = [&](int k0) {  // wave-uniform
+        const int tok0 = k0 % TV_TOKP;
+        const bool tail = k0 + 64 > TV_T;
+        const bool has_pad_key = tok0 + 64 > TV_TOK || (k0 + 63) / TV_TOKP >= ntile;
+        return tail || (wave_has_pad_query && has_pad_key);
+    };
+    auto front = [&](const char* Kl, int k0, int half) {  // scores + maximum of one granule
+        scores(Kl, half);
+        masked = granule_masked(k0);
+        if (masked) maximum(k0, std::true_type{});
+        else maximum(k0, std::false_type{});
+    };
+    auto back = [&](const char* Vl, int half) {  // exponentials + P.V of the granule `front` left pending
+        if (masked) exp_pv(Vl, half, std::true_type{});
+        else exp_pv(Vl, half, std::false_type{});
+    };
 
+    int buf = 0, buf_prev = 0;  // ring slots of tiles t and t-1
+    for (int t = 0; t < NT; ++t) {
+        if (t > 0) __syncthreads();  // tile t is in LDS (written one interval ago); slot (t+1) % 3 was last read in interval t-1
+        const int buf_next = buf == NBUF - 1 ? 0 : buf + 1;
+        if (t + 1 < NT) {
+            STORE_TILE(buf_next)
+        }
+        if (t + 2 < NT) {
+            LOAD_TILE(t + 2)
+        }
+        if (wave_active) {
+            const char* Kl = lds + buf * BUFB;
+            const char* Vl = Kl + KT * KROW;
+            if (grp == 0) {
+                front(Kl, t * KT, 0);
+                back(Vl, 0);
+                front(Kl, t * KT + 64, 1);
+                back(Vl, 1);
+            } else {
+                if (t > 0) back(lds + buf_prev * BUFB + KT * KROW, 1);
+                front(Kl, t * KT, 0);
+                back(Vl, 0);
+                front(Kl, t * KT + 64, 1);
+            }
+        }
+        buf_prev = buf;
+        buf = buf_next;
+    }
     if (!wave_active) return;
+    if (grp == 1) back(lds + buf_prev * BUFB + KT * KROW, 1);  // the last granule: its V stays in the ring, nothing is staged any more
+
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = l_run > 0.f ? __builtin_amdgcn_rcpf(l_run) : 0.f;
     // o[db][4*rg + j] = O[q][32db + 8rg + 4hh + j]; pair the lane halves into 16-byte stores; dims >= 80 do not exist
+    // (T % 32 == 0: a wave's 32 queries are all inside the sequence or all outside, so the swaps below see whole waves)
     if (q < TV_T) {
         bf16_t* op = out + ((size_t)img * TV_T + q) * TV_D + head * TV_DH;
 #pragma unroll
@@ -225,9 +268,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
                 const auto ay = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
                 *(uint4*)(op + db * 32 + (rp + hh) * 8) = make_uint4(ax[0], ay[0], ax[1], ay[1]);
             }
-    } else {
-        // lanes without a query still take part in the swaps above?  No: the swaps sit inside `if (q < TV_T)`, so
-        // a wave must be uniform here -- it is: T % 32 == 0, a wave's 32 queries are all inside or all outside.
     }
 }
 
@@ -237,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
 hipError_t launch_attention_tiles(const void* qkv, void* out, const int32_t* ntiles_dev, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     static_assert(TV_T % 32 == 0, "a wave's queries are all real rows or none");
-    if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_tiles, 2 * BUFB); e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_fwd_tiles, dim3(n * TV_H * NQB), dim3(512), 2 * BUFB, s, (const bf16_t*)qkv, (bf16_t*)out, ntiles_dev);
+    if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_tiles, NBUF * BUFB); e != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_fwd_tiles, dim3(n * TV_H * NQB), dim3(512), NBUF * BUFB, s, (const bf16_t*)qkv, (bf16_t*)out, ntiles_dev);
     return hipGetLastError();
 }
