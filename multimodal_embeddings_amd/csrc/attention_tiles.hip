@@ -160,7 +160,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) raw = fmaxf(raw, (MASKED && ((msk >> (16 * u + e)) & 1u)) ? -INFINITY : s[u][e]);
         float mx = fmaxf(m_run, raw * sc);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {   // the other half of the wave holds the other keys of this query: one v_permlane32_swap instead of an LDS round trip
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
         // a query whose keys are all masked so far keeps mx = -inf: use 0 as the reference point (all p = 0)
         mref = mx == -INFINITY ? 0.f : mx;
         const float alpha = __builtin_amdgcn_exp2f(m_run - mref);  // 0 when m_run = -inf
