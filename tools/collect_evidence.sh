@@ -7,6 +7,7 @@ set -e
 OUT=$(realpath -m "$1")
 R=$(pwd)
 export TMPDIR=/tmp
+rm -rf "$OUT"  # gpurun merges into an existing gpurun_out/: stale pass files of an earlier call would be folded in twice
 mkdir -p "$OUT"
 cd /tmp
 for t in bench_c3 bench_c5 bench_neighbours bench_small bench_tilevit; do

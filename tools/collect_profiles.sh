@@ -6,6 +6,7 @@ set -e
 OUT=$(realpath -m "$1")
 R=$(pwd)
 export TMPDIR=/tmp
+rm -rf "$OUT"  # gpurun merges into an existing gpurun_out/: stale pass files of an earlier call would be folded in twice
 mkdir -p "$OUT"
 cd /tmp
 BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
