@@ -42,8 +42,8 @@ __device__ __forceinline__ bool tv_is_pad(int tok_index, int ntile) {
 // O^T += V^T P^T (12 MFMAs beside ~130 vector instructions) -- and ONE barrier per 128-key tile hands the next staged
 // tile over.  With all eight waves in the same order the two waves of a SIMD did matrix work at the same time and
 // vector work at the same time (6.7 k cycles per tile = the SUM of the 2.8 k of MFMA issue and the ~4 k of vector issue
-// of the pair).  Now waves 4-7 run HALF A GRANULE BEHIND waves 0-3: they end an interval with the scores + maximum of
-// the tile's second granule and begin the next one with its exponentials + P.V (32 score registers carried across the
+// of the pair).  Now waves 4-7 run HALF A GRANULE BEHIND waves 0-3: they end an interval with the scores + softmax of
+// the tile's second granule and begin the next one with its P.V (16 registers of packed P carried across the
 // barrier), so on every SIMD one wave's exponentials sit beside the other's MFMAs throughout (guide: stagger by wave
 // >= 4, not by parity).  V of tile t-1 is still read during interval t, so the ring holds THREE tiles (141 KiB).
 __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -116,11 +116,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
     const int g = lane >> 4, li = lane & 15, tq = li >> 2, tp = li & 3;
     const int v_lane_off = (4 * (g >> 1) + tq) * VROW + (16 * (g & 1) + 4 * tp) * 2;
 
-    // state of the 64-key granule whose exponentials + P.V are still to come (waves 4-7 carry it across the barrier)
-    f32x16 s[2];          // s[u][e] = score of key 128 t + 64 half + 32u + (e&3) + 8(e>>2) + 4hh
-    float mref = 0.f;     // reference point of the exponentials
+    // state of the 64-key granule whose P.V is still to come (waves 4-7 carry it across the barrier)
+    f32x16 s[2];          // s[u][e] = score of key 64 g + 32u + (e&3) + 8(e>>2) + 4hh
+    bf16x8 pf[4];         // its probabilities, packed: the B operands of the four P.V steps
     unsigned msk = 0;     // bit 16 u + e: score s[u][e] does not count
-    bool masked = false;  // wave-uniform: this granule can hold a score that does not count
 
     // ---- S^T for the two 32-key sub-tiles of a granule
     auto scores = [&](const char* Kl, int half) {
@@ -137,11 +136,32 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
             s[u] = a;
         }
     };
-    // ---- running maximum + rescale.  Keys past the sequence end (last tile) never count; (padding query, padding key)
-    // pairs are masked.  The mask is a per-lane bit set consulted where a score is USED (maximum, exponential) -- the
-    // score registers themselves, fresh MFMA results, are left alone -- and only granules that can contain a masked pair
-    // take that form of the body.
-    auto maximum = [&](int k0, auto masked_tag) {
+    // ---- P = exp2(s*sc - ref) into pf, returns this lane's part of the row sum
+    auto probabilities = [&](float ref, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float p = __builtin_amdgcn_exp2f(fmaf(s[i >> 1][8 * (i & 1) + j], sc, -ref));
+                if (MASKED && ((msk >> (16 * (i >> 1) + 8 * (i & 1) + j)) & 1u)) p = 0.f;
+                psum += p;
+                pf[i][j] = (bf16_t)p;
+            }
+        return psum;
+    };
+    // ---- online softmax of one granule, DEFER-MAX form (guide T13).  The probabilities are computed against the
+    // reference point the query ALREADY has (m_run), which does not depend on this granule's maximum, so the
+    // exponentials and the maximum's dependent chain (tree, cross-half swap, compare) overlap instead of running one
+    // after the other; m_run only moves -- with the rescale of O and l and a second pass over the probabilities -- when
+    // some query of the wave found a score more than DEFER above its reference (then p <= 2^DEFER = 256: harmless in
+    // f32 sums and in bf16 P).  The first granule always takes that path (m_run = -inf).
+    // Keys past the sequence end (last tile) never count; (padding query, padding key) pairs are masked.  The mask is a
+    // per-lane bit set consulted where a score is USED -- the score registers themselves, fresh MFMA results, are left
+    // alone -- and only granules that can contain a masked pair take that form of the body.
+    constexpr float DEFER = 8.0f;
+    auto softmax = [&](int k0, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         msk = 0;
         if constexpr (MASKED) {
@@ -153,53 +173,46 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
                     if (key >= TV_T || (q_pad && tv_is_pad(key, ntile))) msk |= 1u << (16 * u + e);
                 }
         }
+        // a query with no countable key so far has m_run = -inf: 0 stands in as the reference point (its p are masked)
+        const float ref_old = m_run == -INFINITY ? 0.f : m_run;
+        float psum = probabilities(ref_old, masked_tag);
         // max over the raw scores, scaled once: fl(s * sc) is monotone in s (sc > 0), so this is max_i fl(s_i * sc)
         float raw = -INFINITY;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int e = 0; e < 16; ++e) raw = fmaxf(raw, (MASKED && ((msk >> (16 * u + e)) & 1u)) ? -INFINITY : s[u][e]);
-        float mx = fmaxf(m_run, raw * sc);
+        float mx = raw * sc;
         {   // the other half of the wave holds the other keys of this query: one v_permlane32_swap instead of an LDS round trip
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
-        // a query whose keys are all masked so far keeps mx = -inf: use 0 as the reference point (all p = 0)
-        mref = mx == -INFINITY ? 0.f : mx;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - mref);  // 0 when m_run = -inf
-        m_run = mx;
-        if (__ballot(alpha != 1.0f) != 0) {  // wave-uniform; a multiplication by 1.0f is exact, so skipping it changes nothing
+        if (__ballot(mx > m_run + DEFER) != 0) {  // wave-uniform (-inf + DEFER = -inf: any countable key moves a fresh query)
+            const float m_new = fmaxf(m_run, mx);
+            const float ref = m_new == -INFINITY ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - ref);  // 0 when m_run = -inf, 1 for the lanes that did not move
+            m_run = m_new;
             l_run *= alpha;
 #pragma unroll
             for (int db = 0; db < 3; ++db)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[db][e] *= alpha;
+            psum = probabilities(ref, masked_tag);
         }
+        l_run += psum;
     };
-    // ---- P = exp2(s*sc - m), row sums, O^T += V^T . P^T in 4 steps of 16 keys
-    auto exp_pv = [&](const char* Vl, int half, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        float psum = 0.f;
+    // ---- O^T += V^T . P^T in 4 steps of 16 keys
+    auto pv = [&](const char* Vl, int half) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float pv = __builtin_amdgcn_exp2f(fmaf(s[i >> 1][8 * (i & 1) + j], sc, -mref));
-                if (MASKED && ((msk >> (16 * (i >> 1) + 8 * (i & 1) + j)) & 1u)) pv = 0.f;
-                psum += pv;
-                pf[j] = (bf16_t)pv;
-            }
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int db = 0; db < 3; ++db) {
                 const char* va = Vl + (half * 4 + i) * 16 * VROW + v_lane_off + db * 64;
                 const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)va);
                 const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_AS s16x4*)(va + 8 * VROW));
                 const s16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, o[db], 0, 0, 0);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf[i], o[db], 0, 0, 0);
             }
-        }
-        l_run += psum;
     };
     auto granule_masked = [&](int k0) {  // wave-uniform
         const int tok0 = k0 % TV_TOKP;
@@ -207,16 +220,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
         const bool has_pad_key = tok0 + 64 > TV_TOK || (k0 + 63) / TV_TOKP >= ntile;
         return tail || (wave_has_pad_query && has_pad_key);
     };
-    auto front = [&](const char* Kl, int k0, int half) {  // scores + maximum of one granule
+    auto front = [&](const char* Kl, int k0, int half) {  // scores + softmax of one granule: leaves its P in pf
         scores(Kl, half);
-        masked = granule_masked(k0);
-        if (masked) maximum(k0, std::true_type{});
-        else maximum(k0, std::false_type{});
+        if (granule_masked(k0)) softmax(k0, std::true_type{});
+        else softmax(k0, std::false_type{});
     };
-    auto back = [&](const char* Vl, int half) {  // exponentials + P.V of the granule `front` left pending
-        if (masked) exp_pv(Vl, half, std::true_type{});
-        else exp_pv(Vl, half, std::false_type{});
-    };
+    auto back = [&](const char* Vl, int half) { pv(Vl, half); };  // P.V of the granule `front` left pending
 
     int buf = 0, buf_prev = 0;  // ring slots of tiles t and t-1
     for (int t = 0; t < NT; ++t) {
