@@ -139,8 +139,16 @@ bool gemm_runs_256(const GemmArgs& g, int variant) { return resolve_variant(g, v
 
 hipError_t launch_gemm(int epilogue, const GemmArgs& g, hipStream_t s, int variant) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    const bool automatic = variant == 0;
     variant = resolve_variant(g, variant);
-    if (variant >= 3 && variant <= 6) return launch_gemm256r(epilogue, g, s, variant == 3 ? 0 : (variant == 4 ? 4 : (variant == 5 ? 8 : 6)));
+    if (variant >= 3 && variant <= 6) {
+        int defer = variant == 3 ? 0 : (variant == 4 ? 4 : (variant == 5 ? 8 : 6));
+        // f32 out (K9): the deferred row block LOSES there -- interleaved A/B on the [8192 x 65536] block, 20 launches per arm,
+        // four rounds: 0.911 ms without, 1.00 ms with (tools/k9_ab.py; the mid-round figure that favoured it had measured the
+        // undeferred arm first, cold).  The bf16 epilogues keep it (-3.4 % of the forward's GEMM time, tools/ab_step.py).
+        if (automatic && epilogue == EPI_F32) defer = 0;
+        return launch_gemm256r(epilogue, g, s, defer);
+    }
     if (g.K <= 0 || (g.K % BK) != 0) return hipErrorInvalidValue;
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     dim3 grid(tiles), block(256);

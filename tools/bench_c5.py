@@ -34,7 +34,7 @@ def main():
     rows = n // 8
     sim = torch.empty((rows, n), dtype=torch.float32, device="cuda")
     wr, fl = rows * n * 4.0, 2.0 * rows * n * d
-    for variant, name in ((1, "128 x 128 tiles, several workgroups per CU: one workgroup stores while others compute"), (3, "all stores in the epilogue"), (4, "last row block deferred into the next tile's K loop (default)")):
+    for variant, name in ((1, "128 x 128 tiles, several workgroups per CU: one workgroup stores while others compute"), (3, "all stores in the epilogue (what mme_cosine launches)"), (4, "last row block deferred into the next tile's K loop")):
         eng.set_gemm_variant(variant)
         dt, _ = timed(lambda: eng.cosine(e16[:rows], e16, out=sim), reps=10)
         print(f"K9  cosine row block [{rows} x {n}] f32, variant {variant} ({name}): {dt*1e3:.3f} ms  write {wr/dt/1e12:.2f} TB/s = {wr/dt/8e12*100:.1f} % of 8 TB/s "
