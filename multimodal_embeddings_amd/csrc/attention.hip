@@ -46,6 +46,16 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #define S_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// the other half of the wave (lane ^ 32) holds the other keys of this lane's query: exchange by ONE v_permlane32_swap (vector
+// ALU) instead of __shfl_xor's ds_bpermute round trip through the LDS, whose latency sits on the head's critical path
+__device__ __forceinline__ float other_half(float x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    // after the swap sw[0] = {lo, lo}, sw[1] = {hi, hi}: the value this lane did not have is the one that differs
+    const float a = __uint_as_float(sw[0]), b = __uint_as_float(sw[1]);
+    return (threadIdx.x & 32) ? a : b;
+}
+
+
 // STAMP: diagnostic build -- every wave accumulates s_memtime intervals between seven points of a head
 // iteration (wait, barrier, request issue, S^T, softmax, P.V, stores) and writes 8 words per wave to `stamps`
 // (layout: mme.h, mme_attention_stamps).  No stamp executes in the product kernel.
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (e + 4 * hh < VIT_T - 192) mx = fmaxf(mx, s[6][e]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = fmaxf(mx, other_half(mx));
                 const float nmx = -mx * sc;
                 float sum4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains: a single one serialises 104 dependent adds
                 // P of step i (16 keys: 8 values per lane), exponentiated, summed and rounded to bf16
@@ -273,7 +283,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
                 pv_step(std::integral_constant<int, 10>{}); pv_step(std::integral_constant<int, 11>{});
                 pv_step(std::integral_constant<int, 12>{});
                 float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
-                sum += __shfl_xor(sum, 32, 64);
+                sum += other_half(sum);
                 inv = __builtin_amdgcn_rcpf(sum);
             } else {
             // S^T tiles; the K fragments of tile kt+1 are requested before the MFMAs of tile kt so
