@@ -74,6 +74,38 @@ def test_shallow_tower_matches_the_oracle_on_padded_and_full_images():
     eng.close()
 
 
+def test_peaked_attention_moves_the_running_maximum_mid_sequence():
+    """The attention kernel computes a granule's probabilities against the reference point the query already has and only
+    moves it (rescale + second pass) when a score lands more than 2^8 above it.  With the seeded weights scores spread
+    over ~3 log2 units, so that path runs once per query; here q_proj and k_proj are scaled by 4 (scores x 16: tens of
+    log2 units of spread), which moves the maximum again and again along the 6432 keys -- on a 4-tile image and on a
+    2-tile image whose padding tiles take the masked form.  Same bar as the other tests: 1e-3 cosine per token."""
+    from multimodal_embeddings_amd._lib import Engine
+    from oracle import mllama_vision as om
+
+    geom = replace(TILE_VIT, num_layers=1, num_global_layers=1, intermediate_layers=(0,))
+    w = dict(make_tile_vit_weights(5, geom))
+    for name in list(w):
+        if name.endswith("self_attn.q_proj.weight") or name.endswith("self_attn.k_proj.weight"):
+            w[name] = (w[name] * np.float32(4.0)).astype(np.float32)  # a power of two: still bf16-representable
+    eng = Engine(0)
+    eng.load_tile_vit(w, geom)
+    rng = np.random.default_rng(9)
+    arrays = [rng.integers(0, 256, s, dtype=np.uint8) for s in [(1000, 1100, 3), (400, 900, 3)]]
+    pv, ids, mask, nt = _prep(eng, arrays)
+    assert nt == [4, 2]
+    hidden, e32, _ = eng.tile_vit_forward(pv, ids, nt, want_hidden=True)
+    torch.cuda.synchronize()
+    host = hidden.cpu().numpy()
+    assert np.isfinite(host).all()
+    pvh = pv.cpu().numpy()
+    for k in range(2):
+        want = om.vision_forward(pvh[k], int(ids[k]), nt[k], w, geom)
+        cos = _token_cos(host[k], want)
+        assert cos.min() >= 1 - 1e-3, (k, float(cos.min()))
+    eng.close()
+
+
 def test_full_tower_matches_rows_recorded_from_transformers(golden_dir):
     """The full 32 + 8 layer tower with the seeded weights of make_tile_vit_weights(2) on one image per tile
     arrangement (all eight aspect-ratio ids): rows of tokens {0, 1, 800, 1600} of every real tile against what
