@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Randomised parity sweeps of the GPU kernels against the oracle (run on a GPU box; ~1.5 minutes):
 
-    python tools/fuzz_parity.py [k1 neighbours fused pages cluster]
+    python tools/fuzz_parity.py [k1 neighbours fused pages cluster nms]
 
   k1          480 random crop sizes (tiny, extreme aspect, near 224, large): patches and Mllama tiles bit-exact
   neighbours   60 random (N, D, fetch, top_n, groups, duplicates, score windows): indices and values exact
   fused        14 problems of 16-42 k rows: fused K12 form == block form (overflow fallback included)
   pages        25 random page tables (empty pages, > 256 regions, zero areas, foreign types, both metrics): 1e-12
   cluster      40 random page matrices x 2 modes x (auto, fixed k): labels and k exact, heavy ties included
+  nms          60 batches of 1-12 random pages (0-900 boxes each; whole-pixel and fractional boxes, tied scores, 1-6
+               classes, thresholds 0-0.95): kept indices and their order exact
 """
 import os
 import sys
@@ -181,12 +183,41 @@ def fuzz_cluster(eng, emb):
     return bad
 
 
+def fuzz_nms(eng, emb):
+    from oracle import regions as oreg
+
+    rng = np.random.default_rng(77)
+    bad = 0
+    for it in range(60):
+        pages = []
+        for _ in range(int(rng.integers(1, 13))):
+            n = int(rng.choice([0, 1, 2, 17, 64, 65, 300, 900]))
+            c = rng.uniform(0, 1500, (n, 2))
+            wh = rng.uniform(2, 500, (n, 2))
+            boxes = np.concatenate([c - wh / 2, c + wh / 2], axis=1)
+            if rng.integers(0, 2):
+                boxes = np.round(boxes)
+            scores = rng.uniform(0, 1, n)
+            if rng.integers(0, 2):
+                scores = np.round(scores, 1)
+            pages.append((boxes, scores, rng.integers(0, int(rng.integers(1, 7)), n).astype(np.int32)))
+        thr = float(rng.choice([0.0, 0.1, 0.3, 0.5, 0.7, 0.95]))
+        offs = np.zeros(len(pages) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([len(p[1]) for p in pages])
+        got = eng.nms_boxes(np.concatenate([p[0].reshape(-1, 4) for p in pages]), np.concatenate([p[1] for p in pages]),
+                            np.concatenate([p[2] for p in pages]), offs, thr)
+        for p, g in zip(pages, got):
+            if g.tolist() != oreg.nms_keep(p[0], p[1], p[2], thr):
+                bad += 1; print("NMS MISMATCH", it, len(p[1]), thr, flush=True)
+    return bad
+
+
 def main():
     emb = RegionEmbedder()
     eng = emb.engine
     total = 0
     only = set(sys.argv[1:])  # e.g. `python tools/fuzz_parity.py k1` runs one sweep
-    for name, fn in [("k1", fuzz_k1), ("neighbours", fuzz_neighbours), ("fused", fuzz_fused), ("pages", fuzz_pages), ("cluster", fuzz_cluster)]:
+    for name, fn in [("k1", fuzz_k1), ("neighbours", fuzz_neighbours), ("fused", fuzz_fused), ("pages", fuzz_pages), ("cluster", fuzz_cluster), ("nms", fuzz_nms)]:
         if only and name not in only:
             continue
         t0 = time.time()
