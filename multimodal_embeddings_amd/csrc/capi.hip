@@ -302,16 +302,19 @@ void fit_to_canvas(int h, int w, int* nh, int* nw) {
 }
 
 // K1 plan shared by the two preprocessing entry points: scratch image + resampling tables of every crop and the bands of
-// the horizontal pass.  A band is a whole number of K1_H_RPT-row groups.  Crops whose table + one row group fit kHLds
-// bytes form the first launch (table in LDS beside the band; five workgroups per CU at 32 KiB); wider crops get one row
-// group per band in a second launch that reads the table through L1 and whose LDS is sized for the widest of them.
+// the horizontal pass.  A band is a whole number of row groups (the rows one work item filters).  Three classes, one
+// launch each:
+//   0  table + eight rows fit kHLds bytes of LDS: eight-row items, table in LDS beside the band (five workgroups per CU at 32 KiB)
+//   1  table + four rows fit: four-row items, table in LDS
+//   2  wider crops: one four-row group per band, the table read through L1, LDS sized for the widest of them
 struct K1Plan {
     size_t tmp_bytes = 0, tab_bytes = 0;
-    std::vector<HWork> large;  // (the small bands go straight into ctx->h_work)
-    int band_small = 16, band_large = 16, n_small = 0;
+    std::vector<HWork> work[3];
+    int lds[3] = {16, 16, 16};  // largest (table +) band per class
+    int count[3] = {0, 0, 0};
     int kv_max = 0;  // largest K1Layout::kv of the batch (LDS of the vertical pass)
 };
-// MME_K1_HBAND (KiB): tuning switch for the LDS budget of the first launch
+// MME_K1_HBAND (KiB): tuning switch for the LDS budget of classes 0 and 1
 static const int kHLds = (getenv("MME_K1_HBAND") && atoi(getenv("MME_K1_HBAND")) >= 4 ? atoi(getenv("MME_K1_HBAND")) : 32) * 1024;
 
 void plan_crop(mme_ctx* c, K1Plan& p, int i, CropDesc& d) {
@@ -325,20 +328,22 @@ void plan_crop(mme_ctx* c, K1Plan& p, int i, CropDesc& d) {
     p.tmp_bytes += (size_t)d.h * k1_tmp_pitch(d.new_w);
     const int row_bytes = d.w * 3;
     const int tab_lds = k1_h_table_lds(d.w, d.new_w);
-    int rows = ((kHLds - tab_lds) / row_bytes) & ~(K1_H_RPT - 1);
-    const bool small = tab_lds < kHLds && rows >= K1_H_RPT;
-    rows = small ? (rows > 64 ? 64 : rows) : K1_H_RPT;
-    std::vector<HWork>& list = small ? c->h_work : p.large;
-    for (int r = 0; r < d.h; r += rows) list.push_back(HWork{i, r, (d.h - r) < rows ? (d.h - r) : rows});
-    const int bb = (rows < d.h ? rows : d.h) * row_bytes + (small ? tab_lds : 0);
-    int& cap = small ? p.band_small : p.band_large;
-    if (bb > cap) cap = bb;
+    const int fit = tab_lds < kHLds ? (kHLds - tab_lds) / row_bytes : 0;  // rows that fit beside the table
+    const int cls = fit >= K1_H_RPT ? 0 : (fit >= K1_H_RPT_WIDE ? 1 : 2);
+    int rows = cls == 0 ? (fit & ~(K1_H_RPT - 1)) : K1_H_RPT_WIDE;
+    if (rows > 64) rows = 64;
+    for (int r = 0; r < d.h; r += rows) p.work[cls].push_back(HWork{i, r, (d.h - r) < rows ? (d.h - r) : rows});
+    const int bb = (rows < d.h ? rows : d.h) * row_bytes + (cls < 2 ? tab_lds : 0);
+    if (bb > p.lds[cls]) p.lds[cls] = bb;
 }
 
-// copies the band list to the device and runs resample_tables + the horizontal pass (both launches)
+// copies the band lists to the device (class 0 | class 1 | class 2)
 int run_h_pass(mme_ctx* c, K1Plan& p, const uint8_t* pix, int n, hipStream_t s, const char* who) {
-    p.n_small = (int)c->h_work.size();
-    c->h_work.insert(c->h_work.end(), p.large.begin(), p.large.end());
+    c->h_work.clear();
+    for (int k = 0; k < 3; ++k) {
+        p.count[k] = (int)p.work[k].size();
+        c->h_work.insert(c->h_work.end(), p.work[k].begin(), p.work[k].end());
+    }
     int r;
     if ((r = ensure(c, c->tmp, p.tmp_bytes + 16))) return r;
     if ((r = ensure(c, c->htab, p.tab_bytes + 16))) return r;
@@ -347,14 +352,15 @@ int run_h_pass(mme_ctx* c, K1Plan& p, const uint8_t* pix, int n, hipStream_t s, 
         HIP_TRY(c, hipMemcpyAsync(c->hwork.p, c->h_work.data(), c->h_work.size() * sizeof(HWork), hipMemcpyHostToDevice, s));
     return MME_OK;
 }
+// resample_tables + the horizontal pass (one launch per class)
 int launch_h_pass(mme_ctx* c, const K1Plan& p, const uint8_t* pix, int n, hipStream_t s, const char* who) {
     if (p.tab_bytes) HIP_TRY(c, launch_resample_tables((const CropDesc*)c->crops.p, n, (uint8_t*)c->htab.p, s));
     const HWork* work = (const HWork*)c->hwork.p;
-    HIP_TRY(c, launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work, p.n_small, p.band_small, true, (const uint8_t*)c->htab.p, s));
-    const int n_large = (int)c->h_work.size() - p.n_small;
-    hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work + p.n_small, n_large, p.band_large, false,
-                                   (const uint8_t*)c->htab.p, s);
-    if (e != hipSuccess) return fail(c, MME_E_HIP, "%s: horizontal pass (%s); band of %d bytes", who, hipGetErrorString(e), p.band_large);
+    for (int k = 0; k < 3; ++k) {
+        hipError_t e = launch_resize_h(pix, (uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, work, p.count[k], p.lds[k], k, (const uint8_t*)c->htab.p, s);
+        if (e != hipSuccess) return fail(c, MME_E_HIP, "%s: horizontal pass, class %d (%s); %d bytes of LDS", who, k, hipGetErrorString(e), p.lds[k]);
+        work += p.count[k];
+    }
     return MME_OK;
 }
 

@@ -118,13 +118,14 @@ __host__ __device__ inline K1Layout k1_layout(int h, int w, int new_h, int new_w
     L.bytes = (L.vk_off + (int64_t)new_h * L.kv * 4 + 15) & ~(int64_t)15;
     return L;
 }
-constexpr int K1_H_RPT = 4;  // source rows one thread of the horizontal pass filters (bands are whole groups of them)
+constexpr int K1_H_RPT = 8;       // source rows one item of the horizontal pass filters (bands are whole groups of them)
+constexpr int K1_H_RPT_WIDE = 4;  // ... in the second launch (crops whose table + eight rows do not fit the LDS budget)
 // both tap tables of every crop, once per crop (f64 on the device exactly as Resample.c computes them on the host)
 hipError_t launch_resample_tables(const CropDesc* crops, int n, uint8_t* tab, hipStream_t s);
-// horizontal pass over `nwork` bands; lds_bytes = the largest (table +) band among them; table_in_lds: every band's crop
-// keeps its window + coefficient table in LDS beside the band (k1_h_table_lds)
+// horizontal pass over `nwork` bands of ONE class (capi: K1Plan): 0 = eight-row items, table in LDS beside the band;
+// 1 = four-row items, table in LDS; 2 = four-row items, table through L1.  lds_bytes = the largest (table +) band.
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int lds_bytes,
-                           bool table_in_lds, const uint8_t* tab, hipStream_t s);
+                           int cls, const uint8_t* tab, hipStream_t s);
 // multi-tile Mllama output: grid_of int32[n,2] (tiles_h, tiles_w); out f32 [n, max_tiles, 3, T, T]
 hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, const int32_t* grid_of, int n,
                                  const float* lut, float* out, int T, int max_tiles, hipStream_t s);

@@ -140,7 +140,10 @@ __global__ __launch_bounds__(256) void resample_tables(const CropDesc* __restric
 // load: gfx950's vmcnt counts stores too, and with table reads in the loop every item waited for the previous item's
 // stores to complete (one write latency per item).  TAB_LDS = false (very wide crops, whose table does not fit beside
 // four source rows) keeps the table in L1 / L2.
-template <bool TAB_LDS>
+// RPT = source rows one item filters: 8 where the table rides in LDS (the per-item set-up -- window, pointers, packing -- is
+// amortised over twice the multiply-adds; the kernel is vector-ALU bound and two thirds of its instructions were not
+// multiply-adds), 4 for the very wide crops of the second launch (eight of their rows would not fit the LDS).
+template <bool TAB_LDS, int RPT>
 __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix, uint8_t* __restrict__ tmp,
                                                 const CropDesc* __restrict__ crops, const HWork* __restrict__ work,
                                                 const uint8_t* __restrict__ tab) {
@@ -163,26 +166,28 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
     const int nvec = (lead + nbytes + 15) >> 4;
     dma_range_to_lds((const uint4*)a0, (char*)band, nvec, tid);
     const int xw = (c.new_w + 3) & ~3;  // columns rounded up to whole quads (the extra lanes repeat the last column)
-    const int nrg = (wk.nrows + K1_H_RPT - 1) / K1_H_RPT;
+    const int nrg = (wk.nrows + RPT - 1) / RPT;
     const int nitems = nrg * xw;
     const uint8_t* bb = band + lead;
     const int pitch = k1_tmp_pitch(c.new_w);
-    uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * pitch;
+    uint8_t* dst = tmp + c.tmp_off + (int64_t)wk.row0 * pitch;  // wave-uniform base; lane offsets below stay 32-bit
     const int j = tid & 3;  // position in the quad (256 and xw are multiples of 4: quads never straddle items' rows)
+    // lanes j = 0..2 of a quad write the quad's 12 output bytes as three dwords: dword j = (v_j >> 8j) | (v_{j+1} << (24 - 8j))
+    const int sh_own = 8 * j, sh_nb = 24 - 8 * j;
     auto item = [&](int e, Taps t, const uint4* __restrict__ kcol /* this column's coefficient groups, stride new_w */, uint4 k) {
         const int rg = e / xw, xq = e - rg * xw;
-        const int y0 = rg * K1_H_RPT;
+        const int y0 = rg * RPT;
         const int ng = (t.n + 3) >> 2;
-        const uint8_t* p[K1_H_RPT];
+        const uint8_t* p[RPT];
 #pragma unroll
-        for (int r = 0; r < K1_H_RPT; ++r) p[r] = bb + min(y0 + r, wk.nrows - 1) * row_bytes + t.xmin * 3;
-        uint32_t acc[K1_H_RPT][3];
+        for (int r = 0; r < RPT; ++r) p[r] = bb + min(y0 + r, wk.nrows - 1) * row_bytes + t.xmin * 3;
+        uint32_t acc[RPT][3];
 #pragma unroll
-        for (int r = 0; r < K1_H_RPT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1u << (PRECISION_BITS - 1);
+        for (int r = 0; r < RPT; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1u << (PRECISION_BITS - 1);
         for (int g = 0; g < ng; ++g) {
             const uint4 kn = g + 1 < ng ? kcol[(int64_t)(g + 1) * c.new_w] : uint4{0, 0, 0, 0};
 #pragma unroll
-            for (int r = 0; r < K1_H_RPT; ++r) {
+            for (int r = 0; r < RPT; ++r) {
                 const Pix12 d = *(const Pix12*)(p[r] + g * 12);
                 acc[r][0] = mad24(d.a & 0xff, k.x, acc[r][0]);
                 acc[r][1] = mad24((d.a >> 8) & 0xff, k.x, acc[r][1]);
@@ -199,14 +204,24 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
             }
             k = kn;
         }
-        // lanes j = 0..2 of a quad write the quad's 12 output bytes as three dwords
-        const int o = (xq & ~3) * 3 + 4 * j;
+        uint32_t out[RPT];
 #pragma unroll
-        for (int r = 0; r < K1_H_RPT; ++r) {
+        for (int r = 0; r < RPT; ++r) {
             const uint32_t v = clip8u(acc[r][0]) | (clip8u(acc[r][1]) << 8) | (clip8u(acc[r][2]) << 16);
             const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xF9 /* quad_perm [1,2,3,3] */, 0xF, 0xF, true);
-            const uint32_t out = j == 0 ? (v | (nb << 24)) : (j == 1 ? ((v >> 8) | (nb << 16)) : ((v >> 16) | (nb << 8)));
-            if (j < 3 && y0 + r < wk.nrows && o < c.new_w * 3) *(uint32_t*)(dst + (int64_t)(y0 + r) * pitch + o) = out;
+            out[r] = (v >> sh_own) | (nb << sh_nb);  // (j = 3: a value nobody stores)
+        }
+        const uint32_t o = (uint32_t)((xq & ~3) * 3 + 4 * j);
+        if (j < 3 && o < (uint32_t)(c.new_w * 3)) {
+            const uint32_t off0 = (uint32_t)y0 * (uint32_t)pitch + o;
+            if (y0 + RPT <= wk.nrows) {  // wave-uniform in all but a crop's last row group
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) *(uint32_t*)(dst + (off0 + (uint32_t)(r * pitch))) = out[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r)
+                    if (y0 + r < wk.nrows) *(uint32_t*)(dst + (off0 + (uint32_t)(r * pitch))) = out[r];
+            }
         }
     };
     if constexpr (TAB_LDS) {
@@ -500,18 +515,20 @@ hipError_t launch_resample_tables(const CropDesc* crops, int n, uint8_t* tab, hi
 }
 
 hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* crops, const HWork* work, int nwork, int lds_bytes,
-                           bool table_in_lds, const uint8_t* tab, hipStream_t s) {
+                           int cls, const uint8_t* tab, hipStream_t s) {
     if (nwork <= 0) return hipSuccess;
     // lds_bytes = (padded table +) one band; + alignment lead (<= 15) + vector rounding (<= 15) + the last tap group's
     // over-read (<= 9 bytes, zero weights) + the DMA sweep's slack
     const size_t smem = (size_t)lds_bytes + 64 + DMA_SLACK;
-    if (smem > 160 * 1024) return hipErrorInvalidValue;
-    const void* fn = table_in_lds ? (const void*)resize_h<true> : (const void*)resize_h<false>;
+    if (smem > 160 * 1024 || cls < 0 || cls > 2) return hipErrorInvalidValue;
+    const void* fn = cls == 0 ? (const void*)resize_h<true, K1_H_RPT> : (cls == 1 ? (const void*)resize_h<true, K1_H_RPT_WIDE> : (const void*)resize_h<false, K1_H_RPT_WIDE>);
     if (hipError_t e = ensure_dynamic_lds(fn, (int)smem); e != hipSuccess) return e;
-    if (table_in_lds)
-        hipLaunchKernelGGL(resize_h<true>, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
+    if (cls == 0)
+        hipLaunchKernelGGL((resize_h<true, K1_H_RPT>), dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
+    else if (cls == 1)
+        hipLaunchKernelGGL((resize_h<true, K1_H_RPT_WIDE>), dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
     else
-        hipLaunchKernelGGL(resize_h<false>, dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
+        hipLaunchKernelGGL((resize_h<false, K1_H_RPT_WIDE>), dim3(nwork), dim3(256), smem, s, pix, tmp, crops, work, tab);
     return hipGetLastError();
 }
 
