@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void resize_h(const uint8_t* __restrict__ pix,
 // four workgroups per CU still are 24-32 waves.
 // Dynamic LDS: kk[16][kvs] (this band's coefficient rows; kvs = the batch's largest K1Layout::kv) | window.
 template <bool RESIZE>
-__global__ __launch_bounds__(RESIZE ? 512 : 256) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
+__global__ __launch_bounds__(RESIZE ? 512 : 256, RESIZE ? 8 : 1) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
                                                          const CropDesc* __restrict__ crops, const float* __restrict__ lut,
                                                          bf16_t* __restrict__ patches, const uint8_t* __restrict__ tab, int window_bytes,
                                                          int kvs) {
