@@ -15,6 +15,8 @@
 //     accumulator holds 4 consecutive n per lane -> 8-byte bf16x4 / 16-byte f32x4 stores and
 //     bias / residual vector loads.
 //   * XCD-aware bijective tile order: consecutive tiles share the A row panel in one XCD's L2.
+#include <cstdlib>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 #include "kernels.h"
@@ -126,9 +128,12 @@ hipError_t launch_gemm256r(int epilogue, const GemmArgs& g, hipStream_t s, int d
 // accepted for old callers and means 3: the 2-slot-ring kernel it named was folded into gemm256r.hip)
 static int resolve_variant(const GemmArgs& g, int variant) {
     if (variant == 0) {
-        // the 256 kernel wants at least ~2 tiles per CU to amortise its prologue
         const int64_t tiles256 = (int64_t)((g.M + 255) / 256) * ((g.N + 255) / 256);
-        variant = tiles256 >= 256 ? 4 : 1;
+        // 128 tiles: measured on whole embed calls of 16..256 crops (tools/bench_small.py; MME_GEMM_MIN256 sweeps it): with the
+        // threshold at 256, calls of 64 / 96 crops ran their 150- / 225-tile GEMMs on the 128 x 128 kernel and took 11 % / 9 %
+        // longer (that kernel also leaves no LayerNorm partial sums: one more pass over x per LayerNorm)
+        static const int min256 = getenv("MME_GEMM_MIN256") ? atoi(getenv("MME_GEMM_MIN256")) : 128;
+        variant = tiles256 >= min256 ? 4 : 1;
     }
     if (variant == 2) variant = 3;
     if (g.K < 128) variant = 1;  // the 256 kernel streams two K-tiles ahead

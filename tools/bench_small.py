@@ -15,7 +15,12 @@ from multimodal_embeddings_amd.weights import synthetic_crops
 
 def main():
     emb = RegionEmbedder()
-    for n in (1, 16, 48, 256, 1024):
+    variants = [int(v) for v in sys.argv[1:]] or [0]  # GEMM variants to compare (0 = the library's choice by problem size)
+    for variant in variants:
+      emb.engine.set_gemm_variant(variant)
+      if len(variants) > 1:
+          print(f"--- GEMM variant {variant}", flush=True)
+      for n in (1, 16, 32, 48, 64, 96, 128, 192, 256, 1024):
         crops = torch.from_numpy(synthetic_crops(n, seed=0)).cuda()
         for _ in range(3):
             emb.embed_uniform(crops)
