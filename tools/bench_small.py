@@ -20,7 +20,8 @@ def main():
       emb.engine.set_gemm_variant(variant)
       if len(variants) > 1:
           print(f"--- GEMM variant {variant}", flush=True)
-      for n in (1, 16, 32, 48, 64, 96, 128, 192, 256, 1024):
+      sizes = [int(v) for v in os.environ.get("BENCH_SMALL_N", "1,16,32,48,64,96,128,192,256,1024").split(",")]
+      for n in sizes:
         crops = torch.from_numpy(synthetic_crops(n, seed=0)).cuda()
         for _ in range(3):
             emb.embed_uniform(crops)
