@@ -34,6 +34,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -67,6 +68,7 @@ def parse_args(argv=None):
     ap.add_argument("--gemm-variant", type=int, default=0, help="0 auto, 1 128x128, 2 256x256 2-slot ring, 3 256x256 3-deep activation ring")
     ap.add_argument("--no-ln-fusion", action="store_true", help="separate LayerNorm kernel instead of folding it into the GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timeout", type=float, default=570.0, help="seconds the self-started multi-rank run may take before every rank is stopped (0: unbounded)")
     return ap.parse_args(argv)
 
 
@@ -76,14 +78,18 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n: int, argv) -> int:
+def launch_ranks(n: int, argv, timeout_s: float = 0.0) -> int:
     """Start n fresh rank processes of this script (torchrun's environment contract) and relay them.
 
     Runs before torch is imported: this parent never initialises a GPU, and nothing is exec'ed from a
     process that has (the children are new interpreters).  Rank 0's stdout (the one JSON line) passes
     through -- only its JSON line: a backend that chats on stdout (gloo prints its connection banner there) must not
     break the one-line contract; the other ranks' stdout goes to stderr.  Replaces the reference's in-process device
-    fan-out (deprecated_package/embedder.py:191-224) with one process per GPU."""
+    fan-out (deprecated_package/embedder.py:191-224) with one process per GPU.
+
+    Every rank is polled while rank 0 is relayed: the first non-zero exit stops the others at once and becomes the return
+    code (a rank that dies would otherwise leave the rest inside the collective); `timeout_s` > 0 bounds the whole run
+    (return code 124)."""
     port = free_port()
     procs = []
     for r in range(n):
@@ -92,23 +98,49 @@ def launch_ranks(n: int, argv) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
-    rc = 0
-    try:
-        for line in procs[0].stdout:  # ends when rank 0 closes its stdout
+
+    def relay():  # rank 0's stdout, on a thread of its own: the main thread must keep watching EVERY rank meanwhile
+        for line in procs[0].stdout:
             (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
             sys.stdout.flush()
-        for p in procs:
-            code = p.wait()
-            rc = rc or code
-            if code:  # one rank died: the others would wait in a collective forever
-                for q in procs:
-                    if q.poll() is None:
-                        q.terminate()
-    except KeyboardInterrupt:
+
+    def stop_all():
         for q in procs:
             if q.poll() is None:
                 q.terminate()
+        t_kill = time.monotonic() + 5.0
+        for q in procs:
+            try:
+                q.wait(timeout=max(0.0, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                q.kill()  # exactly the children started above, by handle: never by pattern
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout_s if timeout_s and timeout_s > 0 else None
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:  # one rank died: the others would sit in the collective until RCCL's watchdog fires
+                r, c = bad[0]
+                print(f"bench.py: rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr, flush=True)
+                stop_all()
+                rc = c if c > 0 else 128 - c  # a signal's negative code reported the shell's way
+                break
+            if all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.monotonic() > deadline:
+                print(f"bench.py: --timeout {timeout_s:g} s exceeded; stopping all ranks", file=sys.stderr, flush=True)
+                stop_all()
+                rc = 124
+                break
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        stop_all()
         rc = 130
+    reader.join(timeout=5.0)
     return rc
 
 
@@ -212,7 +244,7 @@ def cpu_baseline(sample_crops, weights, budget_s: float = 14.0):
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.timeout))
 
     import numpy as np
     import torch

@@ -20,6 +20,10 @@ Fixtures written
   linkage_cases.npz      seeded matrices -> scipy linkage Z, sklearn labels, silhouette
   pagesim_cases.npz      region tables + seeded unit vectors -> S from the REAL
                          compute_image_similarity_matrix over a brute-force collection
+  pagesim_bf16_cases.npz the same table (and a 48-page D = 768 one) with the rows ROUNDED TO BF16, as the device holds them, and
+                         inner products of the stored rows as the collection's cosine -> S from the REAL
+                         compute_image_similarity_matrix and labels from the REAL cluster_images on that S
+                         (`--only-pagesim-bf16`)
   last_pooling.npz       REAL embedder.last_pooling on a seeded tensor
   vit_cases.npz          transformers.ViTModel (seeded synthetic weights) hidden states / embeddings
   crops/*.png            a few bundled region crops (data) incl. the 16 crops of config C1
@@ -85,16 +89,21 @@ def import_reference():
 class FakeCollection:
     """Duck-typed exact-kNN stand-in for the chroma collection."""
 
-    def __init__(self, ids, emb, metas, metric):
+    def __init__(self, ids, emb, metas, metric, renormalise=True):
         self.ids, self.emb, self.metas, self.metric = ids, np.asarray(emb, dtype=np.float64), metas, metric
-        self.norm = self.emb / np.linalg.norm(self.emb, axis=1, keepdims=True)
+        # renormalise=False: the rows are taken as stored (bf16-rounded unit rows: what the GPU table holds) and the
+        # "cosine" is their plain inner product -- north_star's definition of the compare step (an MFMA GEMM over
+        # L2-normalised rows), so the REAL function sees exactly the numbers the device kernel is asked to produce
+        self.renormalise = renormalise
+        self.norm = self.emb / np.linalg.norm(self.emb, axis=1, keepdims=True) if renormalise else self.emb
 
     def get(self, include=None, where=None, ids=None):
         return {"ids": list(self.ids), "metadatas": list(self.metas), "embeddings": [e.tolist() for e in self.emb]}
 
     def query(self, query_embeddings, n_results, include=None, where=None):
         q = np.asarray(query_embeddings[0], dtype=np.float64)
-        q = q / np.linalg.norm(q)
+        if self.renormalise:
+            q = q / np.linalg.norm(q)
         (key, cond), = where.items()
         rows = np.array([i for i, m in enumerate(self.metas) if m.get(key) == cond["$eq"]], dtype=np.int64)
         cos = self.norm[rows] @ q
@@ -527,6 +536,61 @@ def golden_nms():
     print("nms:", len(cases), "cases,", sum(len(c["scores"]) for c in cases), "boxes")
 
 
+def bf16_round(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def golden_pagesim_bf16(w):
+    """pagesim_bf16_cases.npz: the REAL compute_image_similarity_matrix (wrc:97-254) and the REAL cluster_images
+    (wrc:452-574) fed the bf16-ROUNDED unit rows the device table holds: the GPU page matrix is then
+    compared with the reference's own output directly, not through the oracle and not through a correlation."""
+    pages = json.load(open(os.path.join(HERE, "region_table.json")))
+    ids, metas, page_of = table_rows(pages)
+    names19 = [p["name"] for p in pages]
+    paths19 = ["/somewhere/" + n for n in names19]
+    pc = {}
+    emb16 = bf16_round(unit_vectors(len(ids), 64, 7, clusters=12))  # same seeded rows as pagesim_cases.npz, rounded
+    pc["real_emb_bf16"] = emb16
+    pc["real_area_percentage"] = np.array([m["area_percentage"] for m in metas])
+    pc["real_page_of"] = page_of
+    for metric in ("cosine", "sqeuclidean"):
+        S, nm = w.compute_image_similarity_matrix(FakeCollection(ids, emb16, metas, metric, renormalise=False), paths19)
+        assert nm == names19
+        pc[f"real_S_{metric}"] = S
+        res = w.cluster_images(S.copy(), list(nm))
+        pc[f"real_labels_{metric}"] = np.array(res["labels"])
+        pc[f"real_k_{metric}"] = np.array(res["n_clusters"])
+    # a larger synthetic table (P = 48 pages, 12..90 regions, D = 192): more top-k boundaries
+    rng = np.random.default_rng(4242)
+    P = 48
+    syn_names = [f"Synthetic Gazette {i:03d} of the bf16 fixture.png" for i in range(P)]
+    counts = rng.integers(12, 91, P)
+    s_ids, s_metas, s_page = [], [], []
+    for p, c in enumerate(counts):
+        for r in range(int(c)):
+            ap = float(np.exp(rng.uniform(np.log(1e-2), np.log(20.0))))
+            s_ids.append(f"region_p{p}_{r}")
+            s_metas.append({"parent_image_name": syn_names[p], "region_type": "plain_text", "area_percentage": ap, "is_region": True})
+            s_page.append(p)
+    s_emb = bf16_round(unit_vectors(len(s_ids), 192, 11, clusters=9))
+    pc["syn_emb_bf16"] = s_emb.astype(np.float32)
+    pc["syn_area_percentage"] = np.array([m["area_percentage"] for m in s_metas])
+    pc["syn_page_of"] = np.array(s_page)
+    S, nm = w.compute_image_similarity_matrix(FakeCollection(s_ids, s_emb, s_metas, "cosine", renormalise=False), ["/x/" + n for n in syn_names])
+    pc["syn_S_cosine"] = S
+    res = w.cluster_images(S.copy(), list(nm))
+    pc["syn_labels_cosine"] = np.array(res["labels"])
+    pc["syn_k_cosine"] = np.array(res["n_clusters"])
+    json.dump({"names": syn_names}, open(os.path.join(HERE, "pagesim_bf16_names.json"), "w"))
+    # bf16 rows are stored as their 16-bit patterns (half the bytes, exact)
+    for k in ("real_emb_bf16", "syn_emb_bf16"):
+        pc[k] = (pc[k].astype(np.float32).view(np.uint32) >> 16).astype(np.uint16)
+    np.savez_compressed(os.path.join(HERE, "pagesim_bf16_cases.npz"), **pc)
+    print("pagesim bf16 cases ok: labels", pc["real_labels_cosine"].tolist(), "k", int(pc["real_k_cosine"]), "| syn k", int(pc["syn_k_cosine"]))
+
+
 def main():
     scratch = tempfile.mkdtemp(prefix="golden_")
     os.chdir(scratch)
@@ -534,6 +598,10 @@ def main():
     w, ref_embedder = import_reference()
     if "--only-tile-vit" in sys.argv:
         golden_tile_vit()
+        shutil.rmtree(scratch, ignore_errors=True)
+        return
+    if "--only-pagesim-bf16" in sys.argv:
+        golden_pagesim_bf16(w)
         shutil.rmtree(scratch, ignore_errors=True)
         return
     if "--only-nms" in sys.argv:
@@ -678,6 +746,7 @@ def main():
         pc[f"syn_S_{metric}"] = S
     np.savez_compressed(os.path.join(HERE, "pagesim_cases.npz"), **pc)
     print("pagesim cases ok")
+    golden_pagesim_bf16(w)
     golden_neighbours()
     golden_regions()
     golden_tiles()

@@ -209,7 +209,13 @@ def test_weighted_clustering_run_writes_reference_artefacts(embedder, golden_dir
     assert json.load(open(tmp_path / "weighted" / "image_names.json")) == names
     saved = json.load(open(tmp_path / "weighted" / "clustering_results.json"))
     assert saved["labels"] == res["labels"] and saved["n_clusters"] == res["n_clusters"] and saved["clusters"] == res["clusters"]
-    assert np.corrcoef(S.ravel(), g["real_S_cosine"].ravel())[0, 1] > 0.995  # bf16 rows vs the f64 reference, as in test_gpu_parity
+    # the reference's own output for these rows rounded to bf16 (pagesim_bf16_cases.npz: the REAL function on the rounded
+    # rows).  The collection path re-normalises its f32 rows on the device before rounding, so a cosine may differ from the
+    # fixture's by one bf16 rounding of an operand (~2e-4 relative): entry-wise bound instead of the exact-pattern check of
+    # test_gpu_parity::test_page_matrix_and_labels_equal_the_reference_on_the_rows_the_device_holds
+    ref16 = np.load(os.path.join(golden_dir, "pagesim_bf16_cases.npz"))["real_S_cosine"]
+    assert np.array_equal(S == 0, ref16 == 0)
+    assert np.mean(np.abs(S - ref16) > 2e-3) <= 0.02, (np.abs(S - ref16).max(), np.mean(np.abs(S - ref16) > 2e-3))
     want = oc.cluster_images(S.copy(), names)
     assert res["labels"] == want["labels"]
     empty = RegionCollection()

@@ -323,7 +323,33 @@ def test_bench_starts_its_own_ranks(tmp_path):
     r = subprocess.run([sys.executable, "-c", code, "--fail"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 3  # a failing rank fails the launch
     a = bench.parse_args(["--gpus", "8"])
-    assert a.gpus == 8 and a.config == "auto" and a.steps == 5
+    assert a.gpus == 8 and a.config == "auto" and a.steps == 5 and a.timeout > 0
+
+
+def test_bench_launcher_fails_fast_when_a_rank_dies(tmp_path):
+    """a rank != 0 that dies mid-run must not leave the parent blocked on rank 0's stdout while rank 0
+    sits in a collective: the launcher polls every rank, stops the rest and returns non-zero within seconds; a run
+    that never ends is bounded by --timeout."""
+    import time
+
+    probe = tmp_path / "probe.py"
+    # rank 0 "hangs in the collective" (sleeps far longer than the test allows); rank 1 dies after it has started
+    probe.write_text("import os, sys, time, signal\n"
+                     "print('started', os.environ['RANK'], flush=True)\n"
+                     "if os.environ['RANK'] == '1' and '--die' in sys.argv:\n"
+                     "    time.sleep(0.5); os.kill(os.getpid(), signal.SIGKILL)\n"
+                     "time.sleep(600)\n")
+    code = ("import sys; sys.path.insert(0, %r); import bench; bench.__file__ = %r; "
+            "sys.exit(bench.launch_ranks(2, sys.argv[2:], float(sys.argv[1])))" % (ROOT, str(probe)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-c", code, "0", "--die"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 137, (r.returncode, r.stderr)  # SIGKILL of rank 1, reported the shell's way
+    assert time.monotonic() - t0 < 15.0
+    assert "rank 1 exited" in r.stderr
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-c", code, "1.5"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 124 and time.monotonic() - t0 < 15.0, (r.returncode, r.stderr)
 
 
 def test_graft_entry_build():

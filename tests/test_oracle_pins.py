@@ -102,6 +102,33 @@ def test_pagesim_matches_reference(golden_dir):
         assert S[2, 3] == 0 and S[4].sum() == 1.0  # same-prefix pair skipped, empty page only has its diagonal
 
 
+def _bf16_rows(bits):
+    return (bits.astype(np.uint32) << 16).view(np.float32)
+
+
+def test_pagesim_on_bf16_rows_matches_reference(golden_dir):
+    """The fixture the GPU page matrix is held to (test_gpu_parity): the REAL functions fed the bf16-rounded rows the
+    device table holds, inner products of the stored rows as the collection's cosine.  The oracle agrees with it on
+    the same numbers (1e-12), labels of the REAL cluster_images included."""
+    from oracle import cluster as oclu
+
+    g = _load(golden_dir, "pagesim_bf16_cases.npz")
+    pages = json.load(open(os.path.join(golden_dir, "region_table.json")))
+    names = [p["name"] for p in pages]
+    e = _bf16_rows(g["real_emb_bf16"]).astype(np.float64)
+    for metric in ("cosine", "sqeuclidean"):
+        S, _ = ocmp.compute_image_similarity_matrix(None, g["real_area_percentage"], g["real_page_of"], names, metric=metric, sim=e @ e.T)
+        assert np.allclose(S, g[f"real_S_{metric}"], rtol=1e-12, atol=1e-15)
+        res = oclu.cluster_images(g[f"real_S_{metric}"].copy(), names)
+        assert res["labels"] == g[f"real_labels_{metric}"].tolist() and res["n_clusters"] == int(g[f"real_k_{metric}"])
+    syn_names = json.load(open(os.path.join(golden_dir, "pagesim_bf16_names.json")))["names"]
+    e = _bf16_rows(g["syn_emb_bf16"]).astype(np.float64)
+    S, _ = ocmp.compute_image_similarity_matrix(None, g["syn_area_percentage"], g["syn_page_of"], syn_names, sim=e @ e.T)
+    assert np.allclose(S, g["syn_S_cosine"], rtol=1e-12, atol=1e-15)
+    res = oclu.cluster_images(g["syn_S_cosine"].copy(), syn_names)
+    assert res["labels"] == g["syn_labels_cosine"].tolist()
+
+
 def test_pagesim_empty_table():
     assert ocmp.compute_image_similarity_matrix(np.zeros((0, 8)), np.zeros(0), np.zeros(0, dtype=int), ["a", "b"]) == (None, None)
 
