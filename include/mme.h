@@ -25,7 +25,12 @@
 extern "C" {
 #endif
 
-#define MME_ABI_VERSION 1
+/* Bumped whenever an export changes its signature, the meaning of an argument or the size of a caller-owned array.
+ * 2 (round 3): mme_profile_read_sync takes the capacity of the caller's arrays (the class count is no longer part of
+ *    the ABI); mme_set_ln_fusion's argument is a MODE (0 / 1 / 2, it was on / off in version 1); mme_tile_vit_weights
+ *    carries the save point of the intermediate states; the experiment switches MME_GEMM_DEBUG / MME_ATTN_DEBUG exist
+ *    only in a -DMME_DIAG build.  A binder checks `mme_abi_version() == MME_ABI_VERSION` right after dlopen. */
+#define MME_ABI_VERSION 2
 
 enum {
     MME_OK = 0,
@@ -42,6 +47,10 @@ typedef struct mme_ctx mme_ctx;
  * Replaces MmE5MllamaEmbedder.__init__'s per-device replica set-up
  * (deprecated_package/embedder.py:42-84): one context per visible GPU. */
 int mme_abi_version(void);
+/* 1 when the library was built with -DMME_DIAG (libmme_diag.so): only then are the experiment switches of DESIGN.md
+ * 4.5 (MME_GEMM_DEBUG, MME_GEMM_GN / RB / GRID / MIN256, MME_ATTN_BUFS / PIPE / DEBUG, MME_K1_VWIN / HBAND) read from
+ * the environment.  The production library ignores them. */
+int mme_is_diag_build(void);
 int mme_create(int device, mme_ctx** out);
 void mme_destroy(mme_ctx* ctx);
 const char* mme_last_error(const mme_ctx* ctx); /* ctx may be NULL: creation errors */
@@ -293,6 +302,8 @@ int mme_attention_stamps(mme_ctx* ctx, int B, int iters, double* avg_ms, uint64_
  * Host f32 tensors in the Hugging Face state-dict layout: Linear weights [out, in]; patch_w [1280, 3*14*14] in
  * (c, ky, kx) order; pos_emb [1601, 1280]; tile_pos_emb [9, 4*1601*1280]; pre_emb / post_emb [9, 4*1280].
  * Values are rounded to bf16 on upload; the tanh gates are folded into the tables / weights they scale. */
+enum { MME_TILE_SAVE_AFTER_LAYER = 0, MME_TILE_SAVE_BEFORE_LAYER = 1 };
+
 typedef struct {
     const float *ln1_g, *ln1_b;           /* input_layernorm */
     const float *q_w, *k_w, *v_w, *o_w;   /* no biases */
@@ -313,6 +324,14 @@ typedef struct {
     int32_t layers, global_layers;
     int32_t n_intermediate;
     int32_t intermediate[8];
+    /* Which state `intermediate[k] = i` names.  MME_TILE_SAVE_AFTER_LAYER: the OUTPUT of local layer i -- what
+     * transformers 5.15's MllamaVisionEncoder collects (`encoder_states` is appended after each layer; the version the
+     * oracle and tests/golden/tile_vit_cases.npz are pinned to).  MME_TILE_SAVE_BEFORE_LAYER: the state ENTERING local
+     * layer i (= the output of layer i - 1; i = 0: the embeddings after layernorm_pre) -- the convention of encoders that
+     * record the state before running a layer (reported for the first Mllama releases around transformers 4.45 and the
+     * original model code; NOT verifiable offline, "parity unpinned": tested against the oracle's own restatement only).
+     * A binder picks the convention of the transformers version its checkpoint's features were produced with. */
+    int32_t intermediate_save_point;
     float norm_eps;      /* 1e-5 (the encoder layers; layernorm_pre / _post use torch's default 1e-5 too) */
     float pos_gate, pre_gate, post_gate;
     const float* class_embedding;
@@ -362,8 +381,10 @@ int mme_allgather(mme_ctx* ctx, void* comm, const uint16_t* shard_dev, int64_t r
 #define MME_NUM_KERNEL_CLASSES 10
 int mme_profile_enable(mme_ctx* ctx, int on);
 int mme_profile_reset(mme_ctx* ctx);
-/* synchronises the recorded events; ms[c] = total ms, launches[c] = launch count per class */
-int mme_profile_read_sync(mme_ctx* ctx, double ms[MME_NUM_KERNEL_CLASSES], int64_t launches[MME_NUM_KERNEL_CLASSES]);
+/* synchronises the recorded events; ms[c] = total ms, launches[c] = launch count per class, for the first
+ * min(count, MME_NUM_KERNEL_CLASSES) classes: `count` is the capacity of BOTH caller arrays, so a binder built against
+ * a header with fewer classes is never overrun.  Returns the number of classes the library knows (>= 0) or MME_E_*. */
+int mme_profile_read_sync(mme_ctx* ctx, int count, double* ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -12,9 +12,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmme.so")
+# MME_LIB_PATH: measurement tools point this at libmme_diag.so (build.py --diag), the only build that reads the
+# experiment switches of DESIGN.md 4.5; the product default is the in-tree libmme.so
+LIB_PATH = os.environ.get("MME_LIB_PATH") or os.path.join(_HERE, "libmme.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "libmme_diag.so")
 
 NUM_KERNEL_CLASSES = 10
+ABI_VERSION = 2  # include/mme.h MME_ABI_VERSION this binding was written against
 KERNEL_CLASSES = ("preprocess", "gemm", "layernorm", "attention", "pool", "cosine", "page_reduce", "cluster", "neighbours", "allgather")
 
 
@@ -48,7 +52,7 @@ class _TileWeights(C.Structure):
     _fields_ = [
         ("image_size", C.c_int32), ("patch_size", C.c_int32), ("hidden", C.c_int32), ("heads", C.c_int32), ("mlp", C.c_int32),
         ("max_tiles", C.c_int32), ("aspect_ratios", C.c_int32), ("layers", C.c_int32), ("global_layers", C.c_int32),
-        ("n_intermediate", C.c_int32), ("intermediate", C.c_int32 * 8), ("norm_eps", C.c_float),
+        ("n_intermediate", C.c_int32), ("intermediate", C.c_int32 * 8), ("intermediate_save_point", C.c_int32), ("norm_eps", C.c_float),
         ("pos_gate", C.c_float), ("pre_gate", C.c_float), ("post_gate", C.c_float),
         ("class_embedding", C.POINTER(C.c_float)), ("patch_w", C.POINTER(C.c_float)), ("pos_emb", C.POINTER(C.c_float)),
         ("tile_pos_emb", C.POINTER(C.c_float)), ("pre_emb", C.POINTER(C.c_float)), ("post_emb", C.POINTER(C.c_float)),
@@ -59,6 +63,7 @@ class _TileWeights(C.Structure):
 
 EXPORTS = {
     "mme_abi_version": (C.c_int, []),
+    "mme_is_diag_build": (C.c_int, []),
     "mme_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mme_destroy": (None, [C.c_void_p]),
     "mme_last_error": (C.c_char_p, [C.c_void_p]),
@@ -96,7 +101,7 @@ EXPORTS = {
     "mme_attention_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "mme_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_profile_reset": (C.c_int, [C.c_void_p]),
-    "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "mme_profile_read_sync": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -123,8 +128,9 @@ def load_library(path: str | None = None):
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.mme_abi_version() != 1:
-        raise MmeError(f"libmme ABI version {lib.mme_abi_version()} != 1")
+    if lib.mme_abi_version() != ABI_VERSION:
+        raise MmeError(f"libmme ABI version {lib.mme_abi_version()} != {ABI_VERSION} (include/mme.h MME_ABI_VERSION): rebuild the library "
+                       "(python -m multimodal_embeddings_amd.build --force) or update the binding")
     if path is None:
         _lib = lib
     return lib
@@ -230,6 +236,7 @@ class Engine:
         W.n_intermediate = len(geom.intermediate_layers)
         for k, v in enumerate(geom.intermediate_layers):
             W.intermediate[k] = int(v)
+        W.intermediate_save_point = {"after": 0, "before": 1}[geom.intermediate_save_point]
         W.norm_eps = float(geom.norm_eps)
         W.pos_gate = float(w["gated_positional_embedding.gate"][0])
         W.pre_gate = float(w["pre_tile_positional_embedding.gate"][0])
@@ -519,5 +526,6 @@ class Engine:
     def profile_read(self):
         ms = (C.c_double * NUM_KERNEL_CLASSES)()
         cnt = (C.c_int64 * NUM_KERNEL_CLASSES)()
-        self._check(self.lib.mme_profile_read_sync(self.h, ms, cnt), "mme_profile_read_sync")
+        rc = self.lib.mme_profile_read_sync(self.h, NUM_KERNEL_CLASSES, ms, cnt)
+        self._check(min(rc, 0), "mme_profile_read_sync")
         return {KERNEL_CLASSES[i]: (ms[i], cnt[i]) for i in range(NUM_KERNEL_CLASSES)}

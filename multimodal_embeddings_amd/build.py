@@ -1,6 +1,9 @@
 """Build libmme.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
 
-    python -m multimodal_embeddings_amd.build [--force]
+    python -m multimodal_embeddings_amd.build [--force] [--diag]
+
+`--diag` builds libmme_diag.so instead (-DMME_DIAG: the only build that reads the experiment switches of DESIGN.md
+4.5 from the environment; measurement tools select it with MME_LIB_PATH).
 
 hipcc cross-compiles gfx950 code objects without a GPU, so this also is the
 "does it build" check of __graft_entry__.build().  The .so stays inside the
@@ -37,8 +40,11 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> str:
     hipcc = _hipcc()
+    OBJ = os.path.join(CSRC, "_obj_diag" if diag else "_obj")
+    LIB = os.path.join(PKG, "libmme_diag.so" if diag else "libmme.so")
+    FLAGS = globals()["FLAGS"] + (["-DMME_DIAG"] if diag else [])
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
@@ -66,5 +72,5 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True)
+    path = build(force="--force" in sys.argv, verbose=True, diag="--diag" in sys.argv)
     print(path)

@@ -414,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     // MME_ATTN_BUFS=3: three K/V buffers (two heads in flight); measured 3 % slower than two, kept for A/B runs
-    const char* nb_env = getenv("MME_ATTN_BUFS");  // read per launch: an A/B run flips it inside one process
+    const char* nb_env = diag_env("MME_ATTN_BUFS");  // read per launch: an A/B run flips it inside one process
     const int nb = nb_env ? atoi(nb_env) : 2;
     // enough workgroups for two per CU-slot: split a crop's heads over 1, 2, 3, 4, 6 or 12 workgroups
     int hsplit = 1;
@@ -422,7 +422,7 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
         hsplit = d;
         if (B * d >= 512) break;
     }
-    const char* pipe_env = getenv("MME_ATTN_PIPE");
+    const char* pipe_env = diag_env("MME_ATTN_PIPE");
     if (pipe_env && atoi(pipe_env) == 0) {  // the phase-by-phase softmax (A/B)
         if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2, false, false>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
         hipLaunchKernelGGL((attn_fwd_t197<2, false, false>), dim3(B * hsplit), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, hsplit,
@@ -443,7 +443,7 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s) {
 
 // diagnostic: the stamped build (two buffers, one workgroup per crop); stamps = uint64[B][8 waves][8], zeroed by the caller
 hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s) {
-    const int dbg = getenv("MME_ATTN_DEBUG") ? atoi(getenv("MME_ATTN_DEBUG")) : 0;
+    const int dbg = diag_env("MME_ATTN_DEBUG") ? atoi(diag_env("MME_ATTN_DEBUG")) : 0;
     if (B <= 0) return hipSuccess;
     if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2, true>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
     hipLaunchKernelGGL((attn_fwd_t197<2, true>), dim3(B), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, B, 1, stamps, dbg);

@@ -315,7 +315,7 @@ struct K1Plan {
     int kv_max = 0;  // largest K1Layout::kv of the batch (LDS of the vertical pass)
 };
 // MME_K1_HBAND (KiB): tuning switch for the LDS budget of classes 0 and 1
-static const int kHLds = (getenv("MME_K1_HBAND") && atoi(getenv("MME_K1_HBAND")) >= 4 ? atoi(getenv("MME_K1_HBAND")) : 32) * 1024;
+static const int kHLds = (diag_env("MME_K1_HBAND") && atoi(diag_env("MME_K1_HBAND")) >= 4 ? atoi(diag_env("MME_K1_HBAND")) : 32) * 1024;
 
 void plan_crop(mme_ctx* c, K1Plan& p, int i, CropDesc& d) {
     d.tmp_off = 0;
@@ -399,6 +399,13 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
 extern "C" {
 
 int mme_abi_version(void) { return MME_ABI_VERSION; }
+int mme_is_diag_build(void) {
+#ifdef MME_DIAG
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int mme_create(int device, mme_ctx** out) {
     if (!out) return fail(nullptr, MME_E_ARG, "mme_create: out is NULL");
@@ -871,6 +878,10 @@ int mme_nms_boxes(mme_ctx* c, const double* boxes, const double* scores, const i
     const size_t n = (size_t)page_offs[pages];
     if (n && (!boxes || !scores || !classes || !keep)) return fail(c, MME_E_ARG, "mme_nms_boxes: null pointer");
     if (!(iou_threshold == iou_threshold)) return fail(c, MME_E_ARG, "mme_nms_boxes: iou_threshold is NaN");
+    // a NaN score has no place in "the highest-scoring box that is left" (3_combine_grids.py:104: max() / list.index
+    // on a NaN depend on where it sits in the list); json.load accepts NaN, so say so instead of ranking garbage
+    for (size_t i = 0; i < n; ++i)
+        if (!(scores[i] == scores[i])) return fail(c, MME_E_ARG, "mme_nms_boxes: scores[%zu] is NaN", i);
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     // one staging block: boxes | scores | classes | order | keep | page_offs | keep_count
@@ -1164,9 +1175,10 @@ int mme_profile_reset(mme_ctx* c) {
     return MME_OK;
 }
 
-int mme_profile_read_sync(mme_ctx* c, double ms[MME_NUM_KERNEL_CLASSES], int64_t launches[MME_NUM_KERNEL_CLASSES]) {
-    if (!c || !ms || !launches) return fail(c, MME_E_ARG, "mme_profile_read_sync: null argument");
-    for (int i = 0; i < MME_NUM_KERNEL_CLASSES; ++i) {
+int mme_profile_read_sync(mme_ctx* c, int count, double* ms, int64_t* launches) {
+    if (!c || !ms || !launches || count < 0) return fail(c, MME_E_ARG, "mme_profile_read_sync: null argument or negative count");
+    const int nc = count < MME_NUM_KERNEL_CLASSES ? count : MME_NUM_KERNEL_CLASSES;
+    for (int i = 0; i < nc; ++i) {
         ms[i] = 0.0;
         launches[i] = 0;
     }
@@ -1176,10 +1188,11 @@ int mme_profile_read_sync(mme_ctx* c, double ms[MME_NUM_KERNEL_CLASSES], int64_t
         HIP_TRY(c, hipEventSynchronize(ev.b));
         float t = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&t, ev.a, ev.b));
+        if (ev.cls >= nc) continue;  // a class the caller's arrays have no slot for
         ms[ev.cls] += t;
         launches[ev.cls] += 1;
     }
-    return MME_OK;
+    return MME_NUM_KERNEL_CLASSES;
 }
 
 }  // extern "C"

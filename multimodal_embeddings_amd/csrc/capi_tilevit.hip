@@ -22,6 +22,7 @@ struct TileLayerDev {
 struct TileVitDev {
     int layers = 0, global_layers = 0, ni = 0;
     int inter_after[TMAXI];
+    int save_before = 0;  // mme_tile_vit_weights.intermediate_save_point
     float eps = 1e-5f;
     float *cls = nullptr, *pre = nullptr, *pos = nullptr, *tilepos = nullptr, *post = nullptr;
     float *lnpre_g = nullptr, *lnpre_b = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr, *zeros = nullptr;
@@ -68,6 +69,9 @@ int mme_load_tile_vit(mme_ctx* c, const mme_tile_vit_weights* w) {
     for (int k = 0; k < w->n_intermediate; ++k)
         if (w->intermediate[k] < 0 || w->intermediate[k] >= w->layers || (k && w->intermediate[k] <= w->intermediate[k - 1]))
             return fail(c, MME_E_ARG, "mme_load_tile_vit: intermediate layer indices must be ascending and inside the local stack");
+    if (w->intermediate_save_point != MME_TILE_SAVE_AFTER_LAYER && w->intermediate_save_point != MME_TILE_SAVE_BEFORE_LAYER)
+        return fail(c, MME_E_ARG, "mme_load_tile_vit: intermediate_save_point must be MME_TILE_SAVE_AFTER_LAYER (0) or MME_TILE_SAVE_BEFORE_LAYER (1), got %d",
+                    w->intermediate_save_point);
     if (!w->class_embedding || !w->patch_w || !w->pos_emb || !w->tile_pos_emb || !w->pre_emb || !w->post_emb || !w->ln_pre_g || !w->ln_pre_b ||
         !w->ln_post_g || !w->ln_post_b || !w->layer)
         return fail(c, MME_E_ARG, "mme_load_tile_vit: null tensor pointer");
@@ -80,6 +84,7 @@ int mme_load_tile_vit(mme_ctx* c, const mme_tile_vit_weights* w) {
     t->global_layers = w->global_layers;
     t->ni = w->n_intermediate;
     for (int k = 0; k < t->ni; ++k) t->inter_after[k] = w->intermediate[k];
+    t->save_before = w->intermediate_save_point;
     t->eps = w->norm_eps;
     int r;
     // gates are applied here, once: the kernels add plain tables
@@ -206,6 +211,11 @@ int mme_tile_vit_forward(mme_ctx* c, const float* pixel_values, const int32_t* a
         int saved = 0;
         for (int l = 0; l < L; ++l) {
             const TileLayerDev& Ld = t->layer[l];
+            // an intermediate state the output concatenates, "before layer l" convention: the state ENTERING local layer l
+            if (t->save_before && l < t->layers && saved < t->ni && t->inter_after[saved] == l) {
+                HIP_TRY(c, hipMemcpyAsync((char*)t->inter.p + (size_t)saved * ws_rows * TD * 2, t->x.p, (size_t)M * TD * 2, hipMemcpyDeviceToDevice, s));
+                ++saved;
+            }
             if (l == t->layers) {  // between the local and the global stack: layernorm_post + post-tile embedding
                 {
                     Timed tm(c, s, KC_LN);
@@ -252,7 +262,7 @@ int mme_tile_vit_forward(mme_ctx* c, const float* pixel_values, const int32_t* a
                 HIP_TRY(c, launch_gemm(need_stats ? res_epi : EPI_BIAS_RES, g, s, c->gemm_variant));
             }
             if (need_stats && (r = stats_after(g))) return r;
-            if (l < t->layers && saved < t->ni && t->inter_after[saved] == l) {  // an intermediate state the output concatenates
+            if (!t->save_before && l < t->layers && saved < t->ni && t->inter_after[saved] == l) {  // "after layer l" convention
                 HIP_TRY(c, hipMemcpyAsync((char*)t->inter.p + (size_t)saved * ws_rows * TD * 2, t->x.p, (size_t)M * TD * 2, hipMemcpyDeviceToDevice, s));
                 ++saved;
             }

@@ -11,6 +11,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// Experiment switches -- environment variables that change the tiling or (MME_GEMM_DEBUG, MME_ATTN_DEBUG) produce wrong
+// results on purpose -- exist only in the diagnostic build (`python -m multimodal_embeddings_amd.build --diag` ->
+// libmme_diag.so, -DMME_DIAG): a stray variable in a user's environment cannot change what libmme.so computes.
+#include <stdlib.h>
+#ifdef MME_DIAG
+static inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* diag_env(const char*) { return nullptr; }
+#endif
+
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 

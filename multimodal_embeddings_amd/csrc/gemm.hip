@@ -132,7 +132,7 @@ static int resolve_variant(const GemmArgs& g, int variant) {
         // 128 tiles: measured on whole embed calls of 16..256 crops (tools/bench_small.py; MME_GEMM_MIN256 sweeps it): with the
         // threshold at 256, calls of 64 / 96 crops ran their 150- / 225-tile GEMMs on the 128 x 128 kernel and took 11 % / 9 %
         // longer (that kernel also leaves no LayerNorm partial sums: one more pass over x per LayerNorm)
-        static const int min256 = getenv("MME_GEMM_MIN256") ? atoi(getenv("MME_GEMM_MIN256")) : 128;
+        static const int min256 = diag_env("MME_GEMM_MIN256") ? atoi(diag_env("MME_GEMM_MIN256")) : 128;
         variant = tiles256 >= min256 ? 4 : 1;
     }
     if (variant == 2) variant = 3;

@@ -467,11 +467,11 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     const int ntiles = tiles_m * tiles_n;
     const int grid = ntiles < 256 ? ntiles : 256;  // one workgroup per CU
     static const int dbg = [] {  // timing experiments only: 1 = no K-loop loads, 2 = every tile reads tile 0 (wrong results!)
-        const int v = getenv("MME_GEMM_DEBUG") ? atoi(getenv("MME_GEMM_DEBUG")) : 0;
+        const int v = diag_env("MME_GEMM_DEBUG") ? atoi(diag_env("MME_GEMM_DEBUG")) : 0;
         if (v) fprintf(stderr, "libmme: MME_GEMM_DEBUG=%d -- GEMM RESULTS ARE INVALID (timing experiment mode)\n", v);
         return v;
     }();
-    static const int gn_env = getenv("MME_GEMM_GN") ? atoi(getenv("MME_GEMM_GN")) : 0;
+    static const int gn_env = diag_env("MME_GEMM_GN") ? atoi(diag_env("MME_GEMM_GN")) : 0;
     // column-group width: the group's weight rows (gn x 256 x K bf16) should stay resident in one
     // XCD's 4 MiB L2 next to the streaming A panels and output lines; never split below 3 tiles
     // (PMC, fc1 4096 crops: L2-miss fetch 15.4 GB at gn = 12 -> 6.2 GB at gn = 6, same time)
@@ -479,7 +479,7 @@ hipError_t launch256r(const GemmArgs& g, hipStream_t s) {
     if (gn < 3) gn = 3;
     if (gn > tiles_n) gn = tiles_n;
     // MME_GEMM_RB: row-panel block of the tile order (0 = one block: column group outermost, the default); read per launch for A/B runs
-    const char* rb_env = getenv("MME_GEMM_RB");
+    const char* rb_env = diag_env("MME_GEMM_RB");
     // measured at 4096 crops: 16 -> -0.4 % GEMM time (8 / 32: +-0) but +5 % requests leaving the L2 (the weight group is
     // re-fetched per block; FETCH_SIZE counts Infinity-Cache hits too) -- inside the noise, so the default stays 0
     const int rb = rb_env ? atoi(rb_env) : 0;
@@ -503,7 +503,7 @@ hipError_t launch_gemm256r_stamped(const GemmArgs& g, unsigned long long* stamps
     // MME_GEMM_GRID: run the stamped build on fewer workgroups (does the epilogue's store cost depend on how
     // many CUs store at the same time?)
     int grid = ntiles < 256 ? ntiles : 256;
-    if (getenv("MME_GEMM_GRID") && atoi(getenv("MME_GEMM_GRID")) > 0 && atoi(getenv("MME_GEMM_GRID")) < grid) grid = atoi(getenv("MME_GEMM_GRID"));
+    if (diag_env("MME_GEMM_GRID") && atoi(diag_env("MME_GEMM_GRID")) > 0 && atoi(diag_env("MME_GEMM_GRID")) < grid) grid = atoi(diag_env("MME_GEMM_GRID"));
     hipLaunchKernelGGL((gemm_bf16_tn_256r<EPI_BIAS, true>), dim3(grid), dim3(512), LDS_BYTES, s, g, tiles_m, tiles_n, gn, 0, stamps);
     return hipGetLastError();
 }

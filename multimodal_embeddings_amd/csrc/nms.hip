@@ -41,11 +41,14 @@ __global__ __launch_bounds__(256) void nms_pages(const double* __restrict__ boxe
     int32_t* ord = order + base;
     int32_t* kp = keep + base;
     for (int i = tid; i < (n + 31) / 32; i += 256) removed[i] = 0;
+    // The rank must be a TOTAL order or order[] is not a permutation and the walk below indexes with stale words: a NaN
+    // score compares false with everything, so it is ranked as -inf here (mme_nms_boxes rejects NaN scores before the
+    // launch; this keeps the kernel in bounds whatever it is handed).
     for (int i = tid; i < n; i += 256) {
-        const double si = sc[i];
+        const double si = sc[i] == sc[i] ? sc[i] : -INFINITY;
         int r = 0;
         for (int j = 0; j < n; ++j) {
-            const double sj = sc[j];
+            const double sj = sc[j] == sc[j] ? sc[j] : -INFINITY;
             r += (sj > si || (sj == si && j < i)) ? 1 : 0;
         }
         ord[r] = i;

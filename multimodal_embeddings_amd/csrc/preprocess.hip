@@ -537,7 +537,7 @@ hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, cons
     if (n <= 0) return hipSuccess;
     // the LDS window is only needed when some crop is resized or partially fills the canvas; the
     // all-224x224 batch keeps the small footprint (more workgroups per CU for a pure stream)
-    static const int win_kb = getenv("MME_K1_VWIN") ? atoi(getenv("MME_K1_VWIN")) : 16;  // tuning switch (KiB per chunk)
+    static const int win_kb = diag_env("MME_K1_VWIN") ? atoi(diag_env("MME_K1_VWIN")) : 16;  // tuning switch (KiB per chunk)
     const int kvs = kv_max < 4 ? 4 : ((kv_max + 3) & ~3);
     if (kvs > MAX_TAPS) return hipErrorInvalidValue;
     const int kk_bytes = VIT_PATCH * kvs * (int)sizeof(int);

@@ -215,6 +215,9 @@ class TileViTGeometry:
     max_num_tiles: int = 4
     max_aspect_ratio_id: int = 8
     intermediate_layers: tuple = (3, 7, 15, 23, 30)
+    # "after": index i names the OUTPUT of local layer i (transformers 5.15, what the fixtures pin);
+    # "before": the state entering layer i (encoders that record before running a layer; include/mme.h)
+    intermediate_save_point: str = "after"
     norm_eps: float = 1e-5
 
     @property

@@ -87,9 +87,12 @@ def vision_forward(pixel_values, aspect_ratio_id: int, num_tiles: int, w: dict, 
     x = torch.nn.functional.pad(x, (0, 0, 0, PP - NP)).reshape(T * PP, D)
     pad = padding_flags(num_tiles, geom)
     keep = []
+    before = getattr(geom, "intermediate_save_point", "after") == "before"
     for i in range(geom.num_layers):
+        if before and i in geom.intermediate_layers:  # the state ENTERING layer i (include/mme.h, MME_TILE_SAVE_BEFORE_LAYER)
+            keep.append(x)
         x = _block(x, w, f"transformer.layers.{i}.", pad, geom)
-        if i in geom.intermediate_layers:
+        if not before and i in geom.intermediate_layers:  # transformers 5.15: encoder_states appended after each layer
             keep.append(x)
     x = _ln(x, _t(w, "layernorm_post.weight"), _t(w, "layernorm_post.bias"), 1e-5).reshape(T, PP, D)
     post = _t(w, "post_tile_positional_embedding.embedding.weight")[aspect_ratio_id].reshape(T, 1, D)

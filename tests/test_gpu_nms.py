@@ -91,3 +91,21 @@ def test_nms_rejects_bad_arguments(engine):
     with pytest.raises(MmeError):
         engine.nms_boxes(np.zeros((2, 4)), np.zeros(2), np.zeros(2, np.int32), [0, 2], float("nan"))
     assert engine.nms_boxes(np.zeros((0, 4)), np.zeros(0), np.zeros(0, np.int32), [0], 0.5) == []
+    # a NaN score (json.load accepts it) would leave the descending-score rank without a total order: rejected by name,
+    # and the call after it works (the walk used to index with never-written order[] slots)
+    rng = np.random.default_rng(5)
+    xy = rng.uniform(0, 900, (300, 2))
+    boxes = np.concatenate([xy, xy + rng.uniform(5, 120, (300, 2))], axis=1)
+    scores = rng.uniform(0.1, 1.0, 300)
+    bad = scores.copy()
+    bad[[7, 150, 299]] = np.nan
+    with pytest.raises(MmeError, match="NaN"):
+        engine.nms_boxes(boxes, bad, np.zeros(300, np.int32), [0, 300], 0.5)
+    kept = engine.nms_boxes(boxes, scores, np.zeros(300, np.int32), [0, 300], 0.5)
+    from oracle import regions as oreg
+
+    assert kept[0].tolist() == oreg.nms_keep(boxes.tolist(), scores.tolist(), [0] * 300, 0.5)
+    inf = scores.copy()
+    inf[3], inf[4] = np.inf, -np.inf  # infinities are ordered: first and last of the walk
+    kept = engine.nms_boxes(boxes, inf, np.zeros(300, np.int32), [0, 300], 0.5)
+    assert kept[0][0] == 3 and kept[0].tolist() == oreg.nms_keep(boxes.tolist(), inf.tolist(), [0] * 300, 0.5)

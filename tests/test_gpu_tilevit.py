@@ -74,6 +74,51 @@ def test_shallow_tower_matches_the_oracle_on_padded_and_full_images():
     eng.close()
 
 
+def test_intermediate_save_point_conventions_match_the_oracle():
+    """`intermediate[k] = i` may name the state AFTER local layer i (transformers 5.15, the pinned convention)
+    or the state ENTERING it (encoders that record before running a layer).  Both are explicit in
+    mme_tile_vit_weights.intermediate_save_point; each is checked against the oracle's restatement of the same
+    convention (the "before" form is unpinned to any transformers release here: parity unpinned, said in mme.h), and
+    the two differ exactly in the intermediate features while the final-state features are identical."""
+    from multimodal_embeddings_amd._lib import Engine, MmeError
+    from oracle import mllama_vision as om
+
+    rng = np.random.default_rng(8)
+    arrays = [rng.integers(0, 256, (500, 640, 3), dtype=np.uint8)]
+    out = {}
+    for point in ("after", "before"):
+        geom = replace(TILE_VIT, num_layers=3, num_global_layers=1, intermediate_layers=(0, 2), intermediate_save_point=point)
+        w = make_tile_vit_weights(5, geom)
+        eng = Engine(0)
+        eng.load_tile_vit(w, geom)
+        pv, ids, mask, nt = _prep(eng, arrays)
+        hidden, e32, _ = eng.tile_vit_forward(pv, ids, nt, want_hidden=True)
+        torch.cuda.synchronize()
+        host = hidden.cpu().numpy()[0]
+        want = om.vision_forward(pv.cpu().numpy()[0], int(ids[0]), nt[0], w, geom)
+        assert _token_cos(host[: nt[0]], want[: nt[0]]).min() >= 1 - 1e-3, point
+        out[point] = host
+        eng.close()
+    D = TILE_VIT.hidden_size
+    a, b = out["after"][:, :, :D], out["before"][:, :, :D]
+    assert np.array_equal(a, b)  # the final state does not depend on the convention
+    ia = out["after"][:, :, D:].reshape(4, 1601, D, 2)
+    ib = out["before"][:, :, D:].reshape(4, 1601, D, 2)
+    assert not np.array_equal(ia[..., 0], ib[..., 0])
+    # "before layer 2" is "after layer 1"; a third run saving after layers (1,) must reproduce it bit for bit
+    geom = replace(TILE_VIT, num_layers=3, num_global_layers=1, intermediate_layers=(1,), intermediate_save_point="after")
+    eng = Engine(0)
+    eng.load_tile_vit(make_tile_vit_weights(5, geom), geom)
+    pv, ids, mask, nt = _prep(eng, arrays)
+    hidden, _, _ = eng.tile_vit_forward(pv, ids, nt, want_hidden=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(hidden.cpu().numpy()[0][:, :, D:], ib[..., 1])
+    eng.close()
+    with pytest.raises((MmeError, KeyError)):
+        bad = replace(TILE_VIT, num_layers=1, num_global_layers=0, intermediate_layers=(0,), intermediate_save_point="sideways")
+        Engine(0).load_tile_vit(make_tile_vit_weights(5, bad), bad)
+
+
 def test_peaked_attention_moves_the_running_maximum_mid_sequence():
     """The attention kernel computes a granule's probabilities against the reference point the query already has and only
     moves it (rescale + second pass) when a score lands more than 2^8 above it.  With the seeded weights scores spread

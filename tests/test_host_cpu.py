@@ -29,7 +29,11 @@ def test_library_exports_every_declared_symbol(built_lib):
     lib = load_library(built_lib)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.mme_abi_version() == 1
+    from multimodal_embeddings_amd._lib import ABI_VERSION
+
+    # the header, the library and the binding name the same ABI version; the product library is not the diagnostic build
+    assert int(re.search(r"#define MME_ABI_VERSION (\d+)", hdr).group(1)) == lib.mme_abi_version() == ABI_VERSION == 2
+    assert lib.mme_is_diag_build() == 0
     assert isinstance(lib.mme_last_error(None), bytes)
 
 

@@ -4,6 +4,10 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _diag import use_diag_library
+
+use_diag_library()  # the MME_* experiment switches below exist only in libmme_diag.so
 import numpy as np
 
 from multimodal_embeddings_amd._lib import Engine
