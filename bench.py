@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: region-crops/sec embedded + all-pairs cosine (BASELINE.json).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5]
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N rank processes itself
 (fresh children, before this process imports torch or touches a GPU) and relays rank 0's JSON
@@ -19,7 +19,15 @@ local rows against the whole table.
             pads the gathered table with seeded synthetic unit rows to 65536 (the shards the
             missing ranks would have sent), so one rank's full C4 share runs on one GPU.
 
-Weights: seeded synthetic ViT-B/16 (no checkpoint can be fetched offline).
+  config c3 (C3): 4096 variable-size crops per GPU (the size distribution of the reference's bundled region crops,
+            synthetic pixels) through the on-GPU resize / normalise / patchify + embed; `preprocess_hbm` is K1 on
+            variable-size crops; a sample of rows is checked against the oracle.
+  config c5 (C5): 65536 synthetic crops in all (65536 / N per rank) -> embed -> one all-gather -> cosine row block ->
+            the weighted page matrix of 512 pages x 128 regions (page pairs sharded, one all-reduce) -> clustering;
+            the line carries stage times and `labels_equal_oracle`.  (`--crops` shrinks it for a rehearsal.)
+
+Weights: seeded synthetic ViT-B/16 (no checkpoint can be fetched offline).  Every line carries `table_row`, the row
+of the table BASELINE.md section 4 specifies for its config and GPU count.
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 MFMA GEMM,
 gemm_bf16_tn_*): algorithmic GEMM FLOPs of a step / the GEMM kernels' summed duration,
@@ -43,6 +51,7 @@ sys.path.insert(0, ROOT)
 C2_CROPS = 4096
 C4_CROPS = 8192
 C4_TABLE = 65536
+C5_CROPS = 65536
 FLOP_FORWARD_PER_CROP = 35_126_083_584  # SURVEY.md 8d (2*MAC, LN/softmax/GELU excluded)
 FLOP_GEMM_PER_CROP = 231_211_008 + 12 * (697_171_968 + 232_390_656 + 2 * 929_562_624)  # K2,K4,K6,K7 launches
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md (dense)
@@ -60,7 +69,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["auto", "c2", "c4"], default="auto", help="auto: c2 on one GPU, c4 on several")
+    ap.add_argument("--config", choices=["auto", "c2", "c3", "c4", "c5"], default="auto", help="auto: c2 on one GPU, c4 on several")
     ap.add_argument("--crops", type=int, default=0, help="crops per GPU (overrides the config's 4096 / 8192)")
     ap.add_argument("--table-rows", type=int, default=-1, help="rows of the table the cosine block runs against "
                     "(-1: by config; rows beyond the gathered shards are seeded synthetic unit rows)")
@@ -146,12 +155,22 @@ def launch_ranks(n: int, argv, timeout_s: float = 0.0) -> int:
 
 def profile_record():
     """Counter-derived figures of THIS command collected in separate rocprofv3 --pmc passes (profiles/current.json,
-    written by tools/profile_record.py: which kernels' build, which passes, which clock).  None when absent."""
+    written by tools/profile_record.py: which kernels' build, which passes, which clock).  None when absent.
+
+    The record names the hash of the kernel sources it was collected on (`source_hash`, build.kernel_source_hash).
+    When the sources of this tree hash differently the record is STALE: it is still printed (marked `stale: true`,
+    with both hashes) but nothing of it feeds `roofline.traffic`."""
     try:
         with open(PROFILE_RECORD) as fh:
-            return json.load(fh)
+            rec = json.load(fh)
     except (OSError, ValueError):
         return None
+    from multimodal_embeddings_amd.build import kernel_source_hash
+
+    here = kernel_source_hash()
+    rec["stale"] = rec.get("source_hash") != here
+    rec["source_hash_of_this_tree"] = here
+    return rec
 
 
 def baseline_metric_name():
@@ -241,6 +260,24 @@ def cpu_baseline(sample_crops, weights, budget_s: float = 14.0):
     }, e
 
 
+def c3_inputs(n, dev):
+    """Config C3: the size distribution of the reference's 1862 bundled region crops (tests/golden/
+    bundled_crop_sizes_hw.npy: a data file, sorted-filename order) cycled to n crops; pixels are seeded synthetic bytes
+    (the crops themselves cannot travel to the GPU box), packed like RegionEmbedder.pack (16-byte aligned)."""
+    import numpy as np
+    import torch
+
+    sizes = np.load(os.path.join(ROOT, "tests", "golden", "bundled_crop_sizes_hw.npy"))
+    hw = sizes[np.arange(n) % len(sizes)].astype(np.int32)
+    nbytes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+    offs = np.zeros(n, dtype=np.int64)
+    offs[1:] = np.cumsum((nbytes[:-1] + 15) // 16 * 16)
+    total = int(offs[-1] + nbytes[-1]) + 16
+    g = torch.Generator(device=dev).manual_seed(0)
+    pix = torch.randint(0, 256, (total,), dtype=torch.uint8, device=dev, generator=g)
+    return pix, offs, hw, nbytes
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -252,7 +289,7 @@ def main():
 
     from multimodal_embeddings_amd import dist as mdist
     from multimodal_embeddings_amd._lib import Engine
-    from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops
+    from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops, synthetic_page_structure
 
     rank, world, local = mdist.init_from_env()
     if world != args.gpus:
@@ -264,9 +301,16 @@ def main():
     torch.cuda.set_device(dev)
 
     config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
-    n = args.crops or (C2_CROPS if config == "c2" else C4_CROPS)
-    table_rows = args.table_rows if args.table_rows >= 0 else (max(C4_TABLE, n * world) if config == "c4" and not args.crops else n * world)
-    table_rows = max(table_rows, n * world)
+    if config == "c5":
+        n = args.crops or C5_CROPS // world
+        table_rows = n * world
+    elif config == "c3":
+        n = args.crops or C2_CROPS
+        table_rows = n * world
+    else:
+        n = args.crops or (C2_CROPS if config == "c2" else C4_CROPS)
+        table_rows = args.table_rows if args.table_rows >= 0 else (max(C4_TABLE, n * world) if config == "c4" and not args.crops else n * world)
+        table_rows = max(table_rows, n * world)
     n_synth = table_rows - n * world
 
     weights = make_vit_weights(seed=1)
@@ -280,11 +324,22 @@ def main():
         eng.set_ln_fusion(False)
 
     start = rank * n
-    crops_host = synthetic_crops(n, seed=0, start=start)
-    pix = torch.empty(n * 224 * 224 * 3 + 16, dtype=torch.uint8, device=dev)
-    pix[: n * 224 * 224 * 3] = torch.from_numpy(crops_host.reshape(-1)).to(dev)
-    offs = np.arange(n, dtype=np.int64) * (224 * 224 * 3)
-    hw = np.tile(np.array([[224, 224]], dtype=np.int32), (n, 1))
+    bytes_in = None
+    if config == "c3":
+        pix, offs, hw, nbytes = c3_inputs(n, dev)
+        bytes_in = float(nbytes.sum())
+        crops_host = None
+    else:
+        # synthetic 224 x 224 x 3 crops, generated in blocks so that 65536 of them never sit in host memory twice
+        pix = torch.empty(n * 224 * 224 * 3 + 16, dtype=torch.uint8, device=dev)
+        crops_host = None
+        for b0 in range(0, n, 4096):
+            blk = synthetic_crops(min(4096, n - b0), seed=0, start=start + b0)
+            if b0 == 0:
+                crops_host = blk
+            pix[b0 * 150528: (b0 + len(blk)) * 150528] = torch.from_numpy(blk.reshape(-1)).to(dev)
+        offs = np.arange(n, dtype=np.int64) * (224 * 224 * 3)
+        hw = np.tile(np.array([[224, 224]], dtype=np.int32), (n, 1))
     e32 = torch.empty((n, 768), dtype=torch.float32, device=dev)
     e16 = torch.empty((n, 768), dtype=torch.bfloat16, device=dev)
     table = torch.empty((table_rows, 768), dtype=torch.bfloat16, device=dev)
@@ -294,9 +349,22 @@ def main():
     sim = torch.empty((n, table_rows), dtype=torch.float32, device=dev)
     gather_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 1))]
     gather_host_s = [0.0]
+    c5 = None
+    if config == "c5":  # page structure of SURVEY.md 8d: P pages x 128 regions over ALL ranks' crops
+        per_page = 128
+        if (n * world) % per_page:
+            raise SystemExit(f"--config c5 needs a multiple of {per_page} crops in total, got {n * world}")
+        area_pct, page_offs, page_names = synthetic_page_structure((n * world) // per_page, per_page, seed=2, duplicated_prefixes=16)
+        c5 = {"S": None, "labels": None, "k": None, "stage_s": {"embed": 0.0, "gather+cosine": 0.0, "page_matrix": 0.0, "cluster": 0.0}}
+        valid = np.ones(n * world, dtype=np.uint8)
 
     def step(i=-1):
+        t_a = time.perf_counter()
         eng.embed(pix, offs, hw, 0, out_f32=e32, out_bf16=e16)
+        if c5 is not None and i >= 0:
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            c5["stage_s"]["embed"] += t_b - t_a
         if world > 1:
             if i >= 0:
                 gather_ev[i][0].record()
@@ -308,6 +376,23 @@ def main():
         else:
             table[:n].copy_(e16)
         eng.cosine(e16, table, out=sim)
+        if c5 is None:
+            return
+        # the compare -> cluster half of the chain (wrc:857-892): page pairs sharded over the ranks, one all-reduce of the
+        # P x P f64 partials, clustering on every rank (one workgroup, milliseconds)
+        if i >= 0:
+            torch.cuda.synchronize()
+            t_c = time.perf_counter()
+            c5["stage_s"]["gather+cosine"] += t_c - t_b
+        S = mdist.page_similarity_sharded(table, area_pct, valid, page_offs, page_names, rank=rank, world=world, engine=eng)
+        if i >= 0:
+            torch.cuda.synchronize()
+            t_d = time.perf_counter()
+            c5["stage_s"]["page_matrix"] += t_d - t_c
+        labels, k, _ = eng.cluster_pages(S)
+        if i >= 0:
+            c5["stage_s"]["cluster"] += time.perf_counter() - t_d
+        c5["S"], c5["labels"], c5["k"] = S, labels, k
 
     def fence():
         torch.cuda.synchronize()
@@ -340,16 +425,17 @@ def main():
         value = total_crops / elapsed
         gemm_ms, gemm_launches = prof["gemm"]
         gemm_ms_step = gemm_ms / steps
-        ach = (FLOP_GEMM_PER_CROP * n) / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms > 0 else None
+        ach = (FLOP_GEMM_PER_CROP * n) / (gemm_ms_step * 1e-3) / 1e12 if gemm_ms > 0 and c5 is None else None
         cos_ms = prof["cosine"][0] / steps if prof["cosine"][1] else None
         cos_bytes = float(n) * table_rows * 4 + float(table_rows) * 768 * 2 + float(n) * 768 * 2  # f32 block written + bf16 rows read
         cosine_hbm = {"achieved": cos_bytes / (cos_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cos_bytes / (cos_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
                       "bytes": cos_bytes, "ms": cos_ms, "block": [n, table_rows]} if cos_ms else None
         pre_ms = prof["preprocess"][0] / steps if prof["preprocess"][1] else None
-        preprocess_hbm = {"achieved": K1_BYTES_PER_CROP * n / (pre_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": K1_BYTES_PER_CROP * n / (pre_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), "bytes": float(K1_BYTES_PER_CROP) * n, "ms": pre_ms} if pre_ms else None
+        k1_bytes = (bytes_in + 301056.0 * n) if bytes_in is not None else float(K1_BYTES_PER_CROP) * n
+        preprocess_hbm = {"achieved": k1_bytes / (pre_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": k1_bytes / (pre_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), "bytes": k1_bytes, "ms": pre_ms} if pre_ms else None
         rec = profile_record()
-        traffic = rec.get("gemm_traffic_per_launch") if rec and rec.get("crops_per_gpu") == n else None
+        traffic = rec.get("gemm_traffic_per_launch") if rec and rec.get("crops_per_gpu") == n and not rec["stale"] and config == "c2" else None
         roofline = {
             "kernel": "gemm_bf16_tn (K2/K4/K6/K7 launches of the ViT forward)",
             "bound": "mfma",
@@ -358,16 +444,25 @@ def main():
             "unit": "TFLOP/s",
             "frac": (ach / MFMA_BF16_PEAK_TFLOPS) if ach else None,
             "traffic": traffic,
-            "traffic_unit": "bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command; see from_profile)",
+            "traffic_unit": "bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command; see from_profile; "
+                            "null when the record is stale or was collected on another workload)",
             "algorithmic_bytes_per_launch": (BYTES_GEMM_PER_CROP * n + BYTES_GEMM_WEIGHTS * (gemm_launches / steps / 49.0)) / (gemm_launches / steps) if gemm_launches else None,
             "launches_per_step": gemm_launches / steps,
             "avg_launch_ms": gemm_ms / gemm_launches if gemm_launches else None,
             "flop_per_launch_avg": FLOP_GEMM_PER_CROP * n / (gemm_launches / steps) if gemm_launches else None,
         }
-        workload = (f"{config.upper()}: {n} synthetic 224x224x3 crops per GPU -> K1 patchify + ViT-B/16 bf16 forward + pool/L2 + "
+        if c5 is not None:
+            # C5's GEMM class also holds K9 and K10's query GEMM: price the forward from its own launches only
+            roofline.update(achieved=None, frac=None, note="C5 mixes K9 / K10 launches into the GEMM class; see the C2 line for the forward's roofline")
+        what = {"c2": "synthetic 224x224x3 crops", "c4": "synthetic 224x224x3 crops", "c5": "synthetic 224x224x3 crops",
+                "c3": "variable-size crops (bundled size distribution, synthetic pixels)"}[config]
+        workload = (f"{config.upper()}: {n} {what} per GPU -> K1 patchify + ViT-B/16 bf16 forward + pool/L2 + "
                     f"[{n} x {table_rows}] cosine; seeded synthetic weights")
+        if config == "c5":
+            workload += f" -> page matrix of {len(page_names)} pages x 128 regions (K10, pair shards + one all-reduce) -> clustering (K11)"
         if n_synth:
             workload += f"; {n_synth} table rows are seeded synthetic unit rows standing in for the shards of absent ranks"
+        forward_frac = FLOP_FORWARD_PER_CROP * (n * steps / elapsed_local) / (MFMA_BF16_PEAK_TFLOPS * 1e12)
         out = {
             "metric": baseline_metric_name(),
             "value": value,
@@ -377,21 +472,25 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if config != "c5" else "strong",
             "vs_baseline": None,
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
                 "workload": workload,
+                "name": config,
                 "crops_per_gpu": n,
                 "table_rows": table_rows,
                 "parallelism": f"dp{world} (crop shards, one all-gather of bf16 embeddings, backend {dist.get_backend()})" if world > 1 else "single GPU",
+                "note": "the default line is C2 (4096 crops per GPU) at N = 1 and C4's per-rank share (8192 crops per GPU, weak scaling) at N > 1; "
+                        "`c4_share_at_this_n` in the N = 1 line is the same 8192-crop share measured in this run, the figure a 1 -> N curve "
+                        "should be read against",
             },
             "ms_per_step_by_rank": [t * 1e3 / steps for t in per_rank],
             "allgather_ms": gather_ms,
             "allgather_host_ms": gather_host_s[0] * 1e3 / steps if world > 1 else None,
             "allgather_bytes": float(n) * world * 768 * 2 if world > 1 else None,
-            "forward_mfma_frac": FLOP_FORWARD_PER_CROP * (n * steps / elapsed_local) / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+            "forward_mfma_frac": forward_frac if c5 is None else None,
             "forward_mfma_frac_note": "forward FLOP x this rank's crops/s / 2.5 PFLOP/s nominal dense peak (no clock adjustment), measured in this run",
             "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
             "cosine_hbm": cosine_hbm,
@@ -399,15 +498,140 @@ def main():
             "roofline": roofline,
             "from_profile": rec,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        parity = None
+        labels_equal = None
+        if world == 1 and config == "c2" and not args.no_cpu_baseline:
             cb, ecpu = cpu_baseline(crops_host, weights)
             out["cpu_baseline"] = cb
             got = e32[: len(ecpu)].cpu().numpy()
-            out["parity_max_1_minus_cos_vs_oracle"] = float(np.max(1.0 - np.sum(got * ecpu, axis=1)))
+            parity = float(np.max(1.0 - np.sum(got * ecpu, axis=1)))
+        elif not args.no_cpu_baseline and config in ("c3", "c5"):
+            # bounded parity sample against the oracle (test infrastructure, used here as the checker only)
+            from oracle import preprocess as opre
+            from oracle import vit as ovit
+
+            idx = [0, 1, 17, n // 2, n - 1]
+            host = pix.cpu().numpy() if config == "c3" else None
+            crops = [host[offs[i]: offs[i] + int(hw[i, 0]) * int(hw[i, 1]) * 3].reshape(int(hw[i, 0]), int(hw[i, 1]), 3) for i in idx] if config == "c3" \
+                else [pix[i * 150528: (i + 1) * 150528].cpu().numpy().reshape(224, 224, 3) for i in idx]
+            want = ovit.vit_embed(np.stack([opre.preprocess_to_patches(c) for c in crops]), weights)
+            parity = float(np.max(1.0 - np.sum(e32[idx].cpu().numpy() * want, axis=1)))
+        if c5 is not None:
+            out["c5"] = c5_checks(c5, eng, table, area_pct, page_offs, page_names, steps, check=not args.no_cpu_baseline)
+            labels_equal = out["c5"].get("labels_equal_oracle")
+        if parity is not None:
+            out["parity_max_1_minus_cos_vs_oracle"] = parity
+        if world == 1 and config == "c2" and not args.crops:
+            out["c4_share_at_this_n"] = c4_share_line(eng, weights, dev, args)
+        # one row per config x GPU count
+        out["table_row"] = {
+            "config": config.upper(), "gpus": world, "crops_per_s": value,
+            "forward_tflops": FLOP_FORWARD_PER_CROP * value / world / 1e12 if c5 is None else None,
+            "forward_pct_of_2p5pf": 100.0 * forward_frac if c5 is None else None,
+            "rocprof_mfma_util": rec.get("forward_mfma_util") if rec and not rec["stale"] else None,
+            "preprocess_gbs": preprocess_hbm["achieved"] if preprocess_hbm else None, "preprocess_pct_hbm": 100.0 * preprocess_hbm["frac"] if preprocess_hbm else None,
+            "cosine_gbs": cosine_hbm["achieved"] if cosine_hbm else None, "cosine_pct_hbm": 100.0 * cosine_hbm["frac"] if cosine_hbm else None,
+            "allgather_ms": gather_ms,
+            "cpu_crops_per_s": out.get("cpu_baseline", {}).get("value"), "cpu_cores": out.get("cpu_baseline", {}).get("cores"),
+            "max_cosine_error_vs_cpu_ref": parity, "labels_equal_oracle": labels_equal,
+        }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def c4_share_line(eng, weights, dev, args):
+    """One rank's share of C4 on this GPU (8192 crops + the [8192 x 65536] block against a table whose other 57344 rows
+    are seeded synthetic unit rows): what the N > 1 lines run per GPU, measured beside the C2 line so that the driver's
+    1 -> N curve has an N = 1 point of the SAME per-GPU workload."""
+    import numpy as np
+    import torch
+
+    from multimodal_embeddings_amd.weights import synthetic_crops
+
+    n, rows = C4_CROPS, C4_TABLE
+    pix = torch.empty(n * 150528 + 16, dtype=torch.uint8, device=dev)
+    for b0 in range(0, n, 4096):
+        pix[b0 * 150528: (b0 + 4096) * 150528] = torch.from_numpy(synthetic_crops(4096, seed=0, start=b0).reshape(-1)).to(dev)
+    offs = np.arange(n, dtype=np.int64) * 150528
+    hw = np.tile(np.array([[224, 224]], dtype=np.int32), (n, 1))
+    e32 = torch.empty((n, 768), dtype=torch.float32, device=dev)
+    e16 = torch.empty((n, 768), dtype=torch.bfloat16, device=dev)
+    table = torch.empty((rows, 768), dtype=torch.bfloat16, device=dev)
+    g = torch.Generator(device=dev).manual_seed(17)
+    table[n:] = eng.normalise_rows(torch.randn(rows - n, 768, generator=g, device=dev))
+    sim = torch.empty((n, rows), dtype=torch.float32, device=dev)
+
+    def step():
+        eng.embed(pix, offs, hw, 0, out_f32=e32, out_bf16=e16)
+        table[:n].copy_(e16)
+        eng.cosine(e16, table, out=sim)
+
+    step()
+    torch.cuda.synchronize()
+    k = max(2, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    return {"value": n / dt, "unit": "region-crops/s", "crops_per_gpu": n, "table_rows": rows, "ms_per_step": dt * 1e3, "steps": k}
+
+
+def c5_checks(c5, eng, table, area_pct, page_offs, page_names, steps, check=True):
+    """Stage times of the C5 chain and -- with the oracle as the checker -- `labels_equal_oracle`: the labels K11 produced
+    equal oracle.cluster_images on the device's page matrix, and a seeded sample of page pairs equals the oracle's pair
+    rule (wrc:199-226) on the kernel's own cosines.  (Every page pair is checked once in tests/test_gpu_pipeline.py.)"""
+    import numpy as np
+
+    S = c5["S"].cpu().numpy()
+    out = {"pages": len(page_names), "regions_per_page": 128, "n_clusters": c5["k"],
+           "stage_ms_per_step": {k: v * 1e3 / steps for k, v in c5["stage_s"].items()}}
+    if not check:
+        return out
+    from multimodal_embeddings_amd.weighted_region_clustering import page_similarity_from_table
+    from oracle import cluster as oclu
+    from oracle import compare as ocmp
+
+    t0 = time.perf_counter()
+    want = oclu.cluster_images(S.copy(), list(page_names))
+    out["labels_equal_oracle"] = bool(want is not None and want["labels"] == [int(v) for v in c5["labels"]] and want["n_clusters"] == c5["k"])
+    out["oracle_cluster_s"] = time.perf_counter() - t0
+    # sampled page pairs, raw values
+    P = len(page_names)
+    N = int(page_offs[-1])
+    valid = np.ones(N, dtype=np.uint8)
+    Sraw = page_similarity_from_table(table, area_pct, valid, page_offs, page_names, normalise=False, engine=eng).cpu().numpy()
+    rng = np.random.default_rng(11)
+    bad = checked = 0
+    for i, j in rng.integers(0, P, (64, 2)):
+        i, j = int(min(i, j)), int(max(i, j))
+        if i == j:
+            continue
+        rows_i = np.arange(page_offs[i], page_offs[i + 1])
+        rows_j = np.arange(page_offs[j], page_offs[j + 1])
+        sims = eng.cosine(table[rows_i[:10].tolist()], table[rows_j.tolist()]).cpu().numpy()
+        full = np.zeros((10, N), dtype=np.float32)
+        full[:, rows_j] = sims
+
+        class _Sim:
+            def __getitem__(self, key):
+                r, cand = key
+                return full[int(r) - int(rows_i[0])][np.asarray(cand)]
+
+        if page_names[i][:20] == page_names[j][:20]:
+            want_ij = 0.0
+        else:
+            terms = ocmp.pair_terms(None, area_pct, rows_i, rows_j, len(rows_j), sim=_Sim())
+            want_ij = float(np.sum(terms)) if terms else 0.0
+        checked += 1
+        if abs(Sraw[i, j] - want_ij) > 1e-13 * max(1.0, abs(want_ij)):
+            bad += 1
+    out["page_pairs_sampled"] = checked
+    out["page_pairs_differing"] = bad
+    out["labels_equal_oracle"] = bool(out["labels_equal_oracle"] and bad == 0)
+    return out
 
 
 if __name__ == "__main__":

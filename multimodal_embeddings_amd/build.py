@@ -26,6 +26,21 @@ HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "ctx.h", os.path.join("..
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/mme.h), names included: what a counter record
+    (profiles/current.json) is valid for.  bench.py compares it with the record's and marks the record stale."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(PKG, "..", "include", "mme.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -196,6 +196,25 @@ def synthetic_crops(n: int, seed: int = 0, size: int = 224, start: int = 0) -> n
     return out.reshape(n, size, size, 3)
 
 
+def synthetic_page_structure(pages: int = 512, per_page: int = 128, seed: int = 2, duplicated_prefixes: int = 0):
+    """The page structure of config C5 (SURVEY.md 8d): `pages` pages of `per_page` regions, page id = idx // per_page.
+
+    Returns (area_percentage f64 [N] on the reference's 0..100 scale (region_processor.py:89-93), page_offs int32
+    [pages + 1], names).  Area fractions are seeded log-uniform in [1e-4, 0.2], scaled down where a page would sum to
+    more than 1; integer provenance (counter hash), so every box and every rank builds the same table.  Page names have
+    distinct first-20-character prefixes (no same-prefix skips, wrc:179-186) except that the first
+    `duplicated_prefixes` odd pages repeat the prefix of the page before them."""
+    n = pages * per_page
+    u = (counter_u64(seed, 0x6100, n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    frac = np.exp(np.log(1e-4) + u * (np.log(0.2) - np.log(1e-4))).reshape(pages, per_page)
+    tot = frac.sum(axis=1, keepdims=True)
+    frac = np.where(tot > 1.0, frac / tot, frac)
+    names = [f"{p:04d} synthetic page of the C5 set.png" for p in range(pages)]
+    for k in range(duplicated_prefixes):
+        names[2 * k + 1] = names[2 * k][:20] + f" second scan {k}.png"
+    return (frac.reshape(-1) * 100.0), (np.arange(pages + 1, dtype=np.int64) * per_page).astype(np.int32), names
+
+
 # ---- the reference's own vision-tower geometry (SURVEY.md 8f-2) --------------------------------------------------
 @dataclass(frozen=True)
 class TileViTGeometry:

@@ -181,6 +181,74 @@ def test_c5_page_matrix_properties_at_full_size(embedder):
         assert Sraw[i, j] == pytest.approx(want, rel=1e-13, abs=1e-18), (i, j)
 
 
+def test_c5_full_size_chain_embed_to_labels_every_page_pair_checked(embedder):
+    """C5 as ONE chain at full size (the chain the reference runs is wrc:857-892 behind the embedder):
+    65 536 synthetic 224 x 224 crops EMBEDDED on the device -> the resident bf16 table -> K10 page matrix of 512 pages x
+    128 regions (16 duplicated 20-character prefixes) -> K11 clustering.  Every one of the 130 816 page pairs' RAW value is
+    checked against oracle.compare.pair_terms (wrc:199-226) fed the kernel's own cosines of the 5 120 query rows, the
+    normalised matrix against wrc:246-252, and the labels against oracle.cluster_images on that matrix."""
+    import time
+
+    from multimodal_embeddings_amd.weights import synthetic_page_structure
+    from multimodal_embeddings_amd.weighted_region_clustering import cluster_images, page_similarity_from_table
+    from oracle import cluster as oc
+    from oracle import compare as ocmp
+
+    eng = embedder.engine
+    P, per = 512, 128
+    N = P * per
+    table = torch.empty((N, 768), dtype=torch.bfloat16, device="cuda")
+    t0 = time.perf_counter()
+    for b0 in range(0, N, 4096):  # crops are generated and uploaded block by block; embeddings stay on the device
+        crops = torch.from_numpy(synthetic_crops(4096, seed=0, start=b0)).cuda()
+        _, e16 = embedder.embed_uniform(crops)
+        table[b0 : b0 + 4096] = e16
+    torch.cuda.synchronize()
+    print(f"embedded {N} crops in {time.perf_counter() - t0:.1f} s (host generation included)")
+    assert torch.isfinite(table.float()).all()
+    area, offs, names = synthetic_page_structure(P, per, seed=2, duplicated_prefixes=16)
+    valid = np.ones(N, dtype=np.uint8)
+    S = page_similarity_from_table(table, area, valid, offs, names, engine=eng).cpu().numpy()
+    Sraw = page_similarity_from_table(table, area, valid, offs, names, normalise=False, engine=eng).cpu().numpy()
+    assert np.array_equal(S, S.T) and np.array_equal(np.diag(S), np.ones(P)) and np.isfinite(S).all()
+    assert all(S[2 * k, 2 * k + 1] == 0 for k in range(16)) and (Sraw > 0).sum() >= P * (P - 1) - 32
+    # the kernel's own cosines of the query rows (first 10 regions of every page, wrc:199) against the whole table
+    qrows = (np.arange(P)[:, None] * per + np.arange(10)[None, :]).reshape(-1)
+    qsim = eng.cosine(table[qrows.tolist()], table).cpu().numpy()  # [5120, 65536] f32
+
+    class _Sim:  # sim[r, rows_j] for a query region r of the page under test
+        def __init__(self, page):
+            self.base = page * 10 - page * per  # row of qsim = page * 10 + (r - page * per)
+
+        def __getitem__(self, key):
+            r, cand = key
+            return qsim[int(r) + self.base][cand]
+
+    t0 = time.perf_counter()
+    worst = 0.0
+    rows = [np.arange(p * per, (p + 1) * per) for p in range(P)]
+    for i in range(P):
+        sim_i = _Sim(i)
+        for j in range(i + 1, P):
+            if names[i][:20] == names[j][:20]:
+                want = 0.0
+            else:
+                terms = ocmp.pair_terms(None, area, rows[i], rows[j], per, sim=sim_i)
+                want = float(np.sum(terms)) if terms else 0.0
+            got = Sraw[i, j]
+            if got != want:
+                worst = max(worst, abs(got - want) / max(abs(want), 1e-300))
+    print(f"oracle pair rule over {P * (P - 1) // 2} page pairs: {time.perf_counter() - t0:.1f} s, worst relative difference {worst:.2e}")
+    assert worst <= 1e-13
+    mx = Sraw[~np.eye(P, dtype=bool)].max()
+    Swant = Sraw / mx
+    np.fill_diagonal(Swant, 1.0)
+    assert np.abs(S - Swant).max() <= 1e-12
+    res = cluster_images(S.copy(), names, engine=eng)
+    want = oc.cluster_images(S.copy(), names)
+    assert res["labels"] == want["labels"] and res["n_clusters"] == want["n_clusters"] and res["clusters"] == want["clusters"]
+
+
 def test_weighted_clustering_run_writes_reference_artefacts(embedder, golden_dir, tmp_path):
     """run_weighted_clustering = body of wrc.main (:857-892) on the bundled 19-page / 1867-region table with the
     seeded vectors of the pagesim golden: files named and encoded like the reference's, contents consistent

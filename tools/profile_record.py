@@ -27,6 +27,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from multimodal_embeddings_amd.build import kernel_source_hash  # noqa: E402
 
 
 def short(name):
@@ -91,7 +93,8 @@ def main():
     gemm_ms_step = sum(v["avg_ms"] * v["dispatches"] for k, v in kernels.items() if k.startswith("gemm_bf16_tn")) / steps
     rec = {
         "what": "separate rocprofv3 passes of `python3 bench.py --steps %d --warmup 1 --no-cpu-baseline` (kernel trace; SQ; GRBM; FETCH_SIZE; WRITE_SIZE), folded by tools/profile_record.py" % (steps - 1),
-        "tag": tag, "git": sha, "crops_per_gpu": crops, "steps_traced": steps,
+        "tag": tag, "git": sha, "source_hash": kernel_source_hash(),  # of csrc/ + mme.h: bench.py marks the record stale when it differs
+        "crops_per_gpu": crops, "steps_traced": steps,
         "gemm_traffic_per_launch": gemm_bytes / gemm_n if gemm_n else None,
         "gemm_launches_traced": gemm_n,
         "gemm_ms_per_step_kernel_trace": gemm_ms_step,
