@@ -77,6 +77,7 @@ def parse_args(argv=None):
     ap.add_argument("--gemm-variant", type=int, default=0, help="0 auto, 1 128x128, 2 256x256 2-slot ring, 3 256x256 3-deep activation ring")
     ap.add_argument("--no-ln-fusion", action="store_true", help="separate LayerNorm kernel instead of folding it into the GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-from-host", action="store_true", help="skip the secondary PCIe-inclusive measurement (value_from_host)")
     ap.add_argument("--timeout", type=float, default=570.0, help="seconds the self-started multi-rank run may take before every rank is stopped (0: unbounded)")
     return ap.parse_args(argv)
 
@@ -523,6 +524,9 @@ def main():
             out["parity_max_1_minus_cos_vs_oracle"] = parity
         if world == 1 and config == "c2" and not args.crops:
             out["c4_share_at_this_n"] = c4_share_line(eng, weights, dev, args)
+        if world == 1 and config in ("c2", "c3") and not args.no_from_host:
+            out["value_from_host"] = from_host_line(eng, config, crops_host, pix if config == "c3" else None,
+                                                    offs if config == "c3" else None, hw if config == "c3" else None, value)
         # one row per config x GPU count
         out["table_row"] = {
             "config": config.upper(), "gpus": world, "crops_per_s": value,
@@ -577,6 +581,41 @@ def c4_share_line(eng, weights, dev, args):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k
     return {"value": n / dt, "unit": "region-crops/s", "crops_per_gpu": n, "table_rows": rows, "ms_per_step": dt * 1e3, "steps": k}
+
+
+def from_host_line(eng, config, crops_host, pix, offs, hw, resident_value):
+    """Secondary, PCIe-INCLUSIVE rate (never `value`): the same crops handed over as host numpy arrays through the
+    reference-shaped entry, RegionEmbedder.get_image_embeddings (embedder.py:141-226) -- packing into pinned memory, H2D,
+    device pass, D2H and the result conversion, pipelined over groups of 4096 crops.  16384 crops per timed call (the
+    4096-crop set four times over), once returning an ndarray (`as_array=True`) and once the reference's list of float
+    lists."""
+    import numpy as np
+
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+
+    if config == "c3":
+        host = pix.cpu().numpy()
+        arrays = [host[offs[i]: offs[i] + int(hw[i, 0]) * int(hw[i, 1]) * 3].reshape(int(hw[i, 0]), int(hw[i, 1]), 3) for i in range(len(offs))]
+    else:
+        arrays = [crops_host[i] for i in range(len(crops_host))]
+    arrays = arrays * 4
+    emb = RegionEmbedder(engine=eng)
+    emb.get_image_embeddings(arrays[: len(arrays) // 2], batch_size=256, as_array=True)  # warm: staging buffers, streams
+    t0 = time.perf_counter()
+    arr, ok = emb.get_image_embeddings(arrays, batch_size=256, as_array=True)
+    dt_arr = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lists = emb.get_image_embeddings(arrays, batch_size=256)
+    dt_list = time.perf_counter() - t0
+    assert ok.all() and all(v is not None for v in lists)
+    same = bool(np.array_equal(arr[: len(arrays) // 4], arr[len(arrays) // 4: len(arrays) // 2]) and np.array_equal(arr[0], np.asarray(lists[0], dtype=np.float32)))
+    mb = sum(a.nbytes for a in arrays) / 1e6
+    return {"value": len(arrays) / dt_arr, "unit": "region-crops/s", "crops": len(arrays), "host_megabytes": mb,
+            "frac_of_resident": len(arrays) / dt_arr / resident_value,
+            "value_float_lists": len(arrays) / dt_list, "frac_of_resident_float_lists": len(arrays) / dt_list / resident_value,
+            "repeats_agree": same,
+            "what": "host uint8 arrays -> get_image_embeddings(batch_size=256): pinned packing + H2D of group g+1 and D2H / conversion of group g-1 "
+                    "under the device pass of group g; PCIe inclusive, never the headline value"}
 
 
 def c5_checks(c5, eng, table, area_pct, page_offs, page_names, steps, check=True):

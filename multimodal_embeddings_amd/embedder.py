@@ -89,6 +89,19 @@ def _load_rgb(item):
     return np.ascontiguousarray(a)
 
 
+class _Null:
+    """Stream / event stand-in where there is no device (host-logic tests): every ordering call is a no-op."""
+
+    def wait_event(self, *_):
+        pass
+
+    def record(self, *_):
+        pass
+
+    def synchronize(self):
+        pass
+
+
 class RegionEmbedder:
     """Drop-in for `MmE5MllamaEmbedder` on one MI355X."""
 
@@ -199,12 +212,221 @@ class RegionEmbedder:
                 "num_tiles": [[int(v)] for v in nt]}
 
     # -- reference surface ------------------------------------------------------------------------
+    def _pipe_state(self, dev_idx):
+        """Per-context staging of the host <-> device pipeline of `_embed_list`: two slots, each a pinned input buffer, its
+        device twin and a pinned result buffer (grown on demand, kept), two copy streams (the H2D and D2H engines run
+        side by side) and the events that order them against the compute stream."""
+        st = getattr(self, "_pipes", None)
+        if st is None:
+            st = self._pipes = {}
+        if dev_idx not in st:
+            t = self.torch
+            dev = t.device(self.devices[dev_idx])
+            if dev.type != "cuda":  # the host-logic tests drive this pipeline with a stand-in engine and no device
+                mk_stream = mk_event = _Null
+            else:
+                mk_stream, mk_event = (lambda: t.cuda.Stream(dev)), t.cuda.Event
+            with self._on(dev):
+                st[dev_idx] = {
+                    "in_stream": mk_stream(), "out_stream": mk_stream(), "compute": None if dev.type == "cuda" else _Null(),
+                    "pin": [None, None], "dev": [None, None], "out": [None, None], "pinned": dev.type == "cuda",
+                    "ev_in": [mk_event(), mk_event()], "ev_done": [mk_event(), mk_event()], "ev_out": [mk_event(), mk_event()],
+                }
+        return st[dev_idx]
+
+    def _on(self, dev, stream=None):
+        """Context manager: `dev` current (and `stream` current on it); nothing to do without a device."""
+        import contextlib
+
+        t = self.torch
+        if dev.type != "cuda":
+            return contextlib.nullcontext()
+        return t.cuda.stream(stream) if stream is not None else t.cuda.device(dev)
+
+    def _stage_group(self, pipe, slot, arrays, device, first_use):
+        """Pack decoded crops into the slot's pinned buffer (16-byte aligned, as `pack`) and start their H2D copy on the
+        input stream.  Returns (device pixels, offs, hw).  The slot's previous occupants are out of the way: the caller
+        acquired the slot after the consumer recorded `ev_done[slot]` (the pass that read the device twin)."""
+        t = self.torch
+        n = len(arrays)
+        hw = np.array([a.shape[:2] for a in arrays], dtype=np.int32).reshape(n, 2)
+        sizes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+        offs = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            offs[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
+        total = int(offs[-1] + sizes[-1]) + 16
+        if pipe["pin"][slot] is None or pipe["pin"][slot].numel() < total:
+            cap = max(total, 1 << 20)
+            pipe["pin"][slot] = t.empty(cap, dtype=t.uint8, pin_memory=pipe["pinned"])
+            pipe["dev"][slot] = t.empty(cap, dtype=t.uint8, device=device)
+        elif not first_use:
+            pipe["ev_in"][slot].synchronize()  # the last H2D out of this pinned buffer has finished (long ago)
+        hv = pipe["pin"][slot].numpy()
+
+        def copy_range(lo, hi):  # large numpy copies release the GIL: a few threads fill the buffer side by side
+            for k in range(lo, hi):
+                o, sz = int(offs[k]), int(sizes[k])
+                hv[o : o + sz] = arrays[k].reshape(-1)
+
+        nbytes = int(sizes.sum())
+        workers = min(4, os.cpu_count() or 1, max(1, nbytes >> 26))  # one thread per 64 MB, at most four
+        if workers > 1:
+            cuts = np.searchsorted(np.cumsum(sizes), np.linspace(0, nbytes, workers + 1)[1:-1]).tolist()
+            bounds = [0] + [int(c) for c in cuts] + [n]
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                list(pool.map(lambda ab: copy_range(*ab), zip(bounds[:-1], bounds[1:])))
+        else:
+            copy_range(0, n)
+        with self._on(device, pipe["in_stream"]):
+            if not first_use:
+                pipe["in_stream"].wait_event(pipe["ev_done"][slot])  # the pass that read the device twin has run
+            pipe["dev"][slot][:total].copy_(pipe["pin"][slot][:total], non_blocking=True)
+            pipe["ev_in"][slot].record(pipe["in_stream"])
+        return pipe["dev"][slot][:total], offs, hw
+
     def _embed_list(self, dev_idx, items):
         """One context's share of a call: [(index, item)] -> [(index, list[float] | None)] (embedder.py:86-139).
 
         The items go through in bounded groups -- at most 16 x batch_size crops and GROUP_BYTES of packed pixels per
         `mme_embed` call -- each decoded, packed and embedded inside its own try/except: a failure (an unreadable
-        file, an out-of-memory MmeError) voids only what it touched."""
+        file, an out-of-memory MmeError) voids only what it touched.
+
+        The reference runs open -> processor -> forward -> `.cpu().tolist()` strictly in series per image
+        (embedder.py:104-137).  Here the host side of group g + 1 (decode on a thread pool, packing into a pinned
+        buffer, H2D on a copy stream) runs on a producer thread UNDER the device pass of group g, and the D2H of group
+        g plus the float lists of group g - 1 behind it: two staging slots, three streams, events between them."""
+        if getattr(self, "encoder", "vit_b16") == "mllama_tiles":
+            return self._embed_list_serial(dev_idx, items)
+        import queue
+        import threading
+
+        t = self.torch
+        engine = self.engines[dev_idx]
+        device = t.device(self.devices[dev_idx])
+        pipe = self._pipe_state(dev_idx)
+        results = []
+        step = max(1, int(self._group_crops))
+        ready = queue.Queue(maxsize=2)
+        slot_free = [threading.Semaphore(1), threading.Semaphore(1)]
+        used = [False, False]
+        stop = threading.Event()
+
+        def load(pair):
+            i, item = pair
+            try:
+                return i, _load_rgb(item)
+            except Exception as e:  # embedder.py:135-137
+                logger.error(f"Error processing image {item if isinstance(item, (str, os.PathLike)) else type(item)}: {e}")
+                return i, None
+
+        def produce():
+            g = 0
+            try:
+                with self._on(device):
+                    for g0 in range(0, len(items), step):
+                        part = items[g0 : g0 + step]
+                        # PNG decode is the slow part of a call and Pillow releases the GIL while decoding
+                        if len(part) > 4 and not all(isinstance(it, np.ndarray) for _, it in part):
+                            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(part))) as pool:
+                                loaded = list(pool.map(load, part))
+                        else:
+                            loaded = [load(pr) for pr in part]
+                        failed = [i for i, a in loaded if a is None]
+                        groups, group, nbytes = [], [], 0
+                        for i, a in loaded:
+                            if a is None:
+                                continue
+                            if group and nbytes + a.nbytes > self.GROUP_BYTES:
+                                groups.append(group)
+                                group, nbytes = [], 0
+                            group.append((i, a))
+                            nbytes += a.nbytes
+                        if group:
+                            groups.append(group)
+                        if failed:
+                            ready.put(("failed", failed))
+                        for group in groups:
+                            slot = g & 1
+                            while not slot_free[slot].acquire(timeout=0.1):
+                                if stop.is_set():
+                                    return
+                            try:
+                                staged = self._stage_group(pipe, slot, [a for _, a in group], device, not used[slot])
+                                used[slot] = True
+                                ready.put(("group", slot, [i for i, _ in group], staged))
+                            except Exception as e:  # embedder.py:223-224
+                                logger.error(f"Error in batch processing: {e}")
+                                slot_free[slot].release()
+                                ready.put(("failed", [i for i, _ in group]))
+                                continue
+                            g += 1
+            except BaseException as e:  # never leave the consumer waiting
+                logger.error(f"Error in batch processing: {e}")
+            finally:
+                ready.put(("end",))
+
+        pending = None  # (slot, indices, n, device result kept alive) whose D2H is in flight
+
+        def finalize(p):
+            slot, idx, n, _keep = p
+            pipe["ev_out"][slot].synchronize()
+            if getattr(self, "_rows_as_array", False):
+                rows = list(pipe["out"][slot][:n].numpy().copy())  # float32 row views (get_image_embeddings(as_array=True))
+            else:
+                rows = pipe["out"][slot][:n].tolist()  # embedder.py:132 `.cpu().tolist()`
+            results.extend(zip(idx, rows))
+
+        producer = threading.Thread(target=produce, name=f"mme-stage-{dev_idx}", daemon=True)
+        producer.start()
+        try:
+            with self._on(device):
+                compute = pipe["compute"] or t.cuda.current_stream(device)
+                while True:
+                    msg = ready.get()
+                    if msg[0] == "end":
+                        break
+                    if msg[0] == "failed":
+                        results.extend((i, None) for i in msg[1])
+                        continue
+                    _, slot, idx, (pix, offs, hw) = msg
+                    n = len(idx)
+                    try:
+                        compute.wait_event(pipe["ev_in"][slot])
+                        e32, _ = engine.embed(pix, offs, hw, self.pool_token, want_bf16=False)
+                        pipe["ev_done"][slot].record(compute)
+                    except Exception as e:  # embedder.py:223-224
+                        logger.error(f"Error in batch processing: {e}")
+                        pipe["ev_done"][slot].record(compute)
+                        slot_free[slot].release()
+                        results.extend((i, None) for i in idx)
+                        continue
+                    slot_free[slot].release()  # the producer may refill the slot: its H2D waits for ev_done on the device
+                    if pending is not None and pending[0] == slot:
+                        finalize(pending)  # the result buffer of this slot is about to be reused
+                        pending = None
+                    if pipe["out"][slot] is None or pipe["out"][slot].shape[0] < n or pipe["out"][slot].shape[1] != e32.shape[1]:
+                        pipe["out"][slot] = t.empty((max(n, 256), e32.shape[1]), dtype=t.float32, pin_memory=pipe["pinned"])
+                    with self._on(device, pipe["out_stream"]):
+                        pipe["out_stream"].wait_event(pipe["ev_done"][slot])
+                        pipe["out"][slot][:n].copy_(e32, non_blocking=True)
+                        pipe["ev_out"][slot].record(pipe["out_stream"])
+                    if pending is not None:
+                        finalize(pending)  # float lists of the previous group, under this group's device pass
+                    pending = (slot, idx, n, e32)
+                if pending is not None:
+                    finalize(pending)
+        finally:
+            stop.set()
+            while producer.is_alive():  # drain so that a blocked put() returns
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            producer.join()
+        return results
+
+    def _embed_list_serial(self, dev_idx, items):
+        """The unpipelined form (decode -> pack -> pass -> lists per group), used by the tile-ViT option."""
         engine = self.engines[dev_idx]
         device = self.torch.device(self.devices[dev_idx])
         results = []
@@ -238,8 +460,6 @@ class RegionEmbedder:
             step = min(step, self.TILE_GROUP_CROPS)
         for g0 in range(0, len(items), step):
             part = items[g0 : g0 + step]
-            # PNG decode is the slow part of a call (the GPU needs ~3 ms for 48 crops) and Pillow releases the GIL
-            # while decoding: decode a group on a small thread pool, keep the order
             if len(part) > 4:
                 with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1, len(part))) as pool:
                     loaded = list(pool.map(load, part))
@@ -258,15 +478,19 @@ class RegionEmbedder:
             run(group)
         return results
 
-    def get_image_embeddings(self, image_paths, is_query=False, batch_size=config.BATCH_SIZE):
+    def get_image_embeddings(self, image_paths, is_query=False, batch_size=config.BATCH_SIZE, *, as_array=False):
         """embedder.py:141-226: order-preserving list of float lists with None holes.
+
+        `as_array=True` (an addition to the reference's signature) returns (float32 [n, D] ndarray, bool [n] mask of
+        the rows that were embedded) instead: building n x D Python floats costs more host time than the device pass.
 
         Item i goes to context i % n_devices (:191-203) and every context works through its share on its own
         thread (:208-224); a single query image takes the first context without the pool (:158-185).
         `batch_size` keeps the reference's meaning "images per GPU per batch", except that a device pass here
         carries 16 of the reference's one-image forwards per unit of it (256 crops at the default 16)."""
         if not image_paths:
-            return []
+            return (np.zeros((0, 768), dtype=np.float32), np.zeros(0, dtype=bool)) if as_array else []
+        self._rows_as_array = bool(as_array) and getattr(self, "encoder", "vit_b16") != "mllama_tiles"
         self._group_crops = 16 * max(1, int(batch_size))
         embeddings = [None] * len(image_paths)
         n_dev = len(self.engines)
@@ -282,6 +506,14 @@ class RegionEmbedder:
         for part in done:
             for i, row in part:
                 embeddings[i] = row
+        if as_array:
+            ok = np.array([row is not None for row in embeddings], dtype=bool)
+            width = next((len(row) for row in embeddings if row is not None), 768)
+            arr = np.zeros((len(embeddings), width), dtype=np.float32)
+            for i, row in enumerate(embeddings):
+                if row is not None:
+                    arr[i] = row
+            return arr, ok
         return embeddings
 
     def embed(self, region):

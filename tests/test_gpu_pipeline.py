@@ -181,6 +181,31 @@ def test_c5_page_matrix_properties_at_full_size(embedder):
         assert Sraw[i, j] == pytest.approx(want, rel=1e-13, abs=1e-18), (i, j)
 
 
+def test_pipelined_groups_equal_one_group_and_keep_the_none_holes(embedder):
+    """get_image_embeddings stages group g + 1 (pack, H2D) and converts group g - 1 (D2H, lists) under the device pass
+    of group g (two staging slots, three streams): many small groups, a byte budget that splits groups, unreadable
+    items in the middle and a second call on the warm staging buffers give the rows of ONE big group bit for bit."""
+    rng = np.random.default_rng(21)
+    arrays = [rng.integers(0, 256, (int(rng.integers(20, 400)), int(rng.integers(20, 400)), 3), dtype=np.uint8) for _ in range(150)]
+    want = embedder.get_image_embeddings(arrays, batch_size=16)  # 256 per group: one group
+    assert all(v is not None for v in want)
+    items = list(arrays)
+    items[17] = "/nonexistent/a.png"
+    items[99] = np.zeros((0, 5, 3), dtype=np.uint8)  # an empty crop fails in _load_rgb
+    for bs, budget in ((1, 1 << 30), (2, 200_000), (1, 1 << 30)):
+        old = embedder.GROUP_BYTES
+        embedder.GROUP_BYTES = budget
+        try:
+            got = embedder.get_image_embeddings(items, batch_size=bs)
+        finally:
+            embedder.GROUP_BYTES = old
+        assert [v is None for v in got] == [i in (17, 99) for i in range(150)]
+        assert all(got[i] == want[i] for i in range(150) if i not in (17, 99))
+    arr, ok = embedder.get_image_embeddings(items, batch_size=1, as_array=True)
+    assert ok.tolist() == [i not in (17, 99) for i in range(150)]
+    assert all(np.array_equal(arr[i], np.asarray(want[i], dtype=np.float32)) for i in range(150) if i not in (17, 99))
+
+
 def test_c5_full_size_chain_embed_to_labels_every_page_pair_checked(embedder):
     """C5 as ONE chain at full size (the chain the reference runs is wrc:857-892 behind the embedder):
     65 536 synthetic 224 x 224 crops EMBEDDED on the device -> the resident bf16 table -> K10 page matrix of 512 pages x
