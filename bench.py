@@ -586,7 +586,7 @@ def c4_share_line(eng, weights, dev, args):
 def from_host_line(eng, config, crops_host, pix, offs, hw, resident_value):
     """Secondary, PCIe-INCLUSIVE rate (never `value`): the same crops handed over as host numpy arrays through the
     reference-shaped entry, RegionEmbedder.get_image_embeddings (embedder.py:141-226) -- packing into pinned memory, H2D,
-    device pass, D2H and the result conversion, pipelined over groups of 4096 crops.  16384 crops per timed call (the
+    device pass, D2H and the result conversion, pipelined over groups of 2048 crops.  16384 crops per timed call (the
     4096-crop set four times over), once returning an ndarray (`as_array=True`) and once the reference's list of float
     lists."""
     import numpy as np
@@ -600,12 +600,12 @@ def from_host_line(eng, config, crops_host, pix, offs, hw, resident_value):
         arrays = [crops_host[i] for i in range(len(crops_host))]
     arrays = arrays * 4
     emb = RegionEmbedder(engine=eng)
-    emb.get_image_embeddings(arrays[: len(arrays) // 2], batch_size=256, as_array=True)  # warm: staging buffers, streams
+    emb.get_image_embeddings(arrays[: len(arrays) // 2], batch_size=128, as_array=True)  # warm: staging buffers, streams
     t0 = time.perf_counter()
-    arr, ok = emb.get_image_embeddings(arrays, batch_size=256, as_array=True)
+    arr, ok = emb.get_image_embeddings(arrays, batch_size=128, as_array=True)
     dt_arr = time.perf_counter() - t0
     t0 = time.perf_counter()
-    lists = emb.get_image_embeddings(arrays, batch_size=256)
+    lists = emb.get_image_embeddings(arrays, batch_size=128)
     dt_list = time.perf_counter() - t0
     assert ok.all() and all(v is not None for v in lists)
     same = bool(np.array_equal(arr[: len(arrays) // 4], arr[len(arrays) // 4: len(arrays) // 2]) and np.array_equal(arr[0], np.asarray(lists[0], dtype=np.float32)))
@@ -614,7 +614,7 @@ def from_host_line(eng, config, crops_host, pix, offs, hw, resident_value):
             "frac_of_resident": len(arrays) / dt_arr / resident_value,
             "value_float_lists": len(arrays) / dt_list, "frac_of_resident_float_lists": len(arrays) / dt_list / resident_value,
             "repeats_agree": same,
-            "what": "host uint8 arrays -> get_image_embeddings(batch_size=256): pinned packing + H2D of group g+1 and D2H / conversion of group g-1 "
+            "what": "host uint8 arrays -> get_image_embeddings(batch_size=128): pinned packing + H2D of group g+1 and D2H / conversion of group g-1 "
                     "under the device pass of group g; PCIe inclusive, never the headline value"}
 
 

@@ -73,6 +73,8 @@ def _load_rgb(item):
         if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
             raise ValueError(f"array crops must be uint8[h,w,3], got {a.dtype}{a.shape}")
         h, w = a.shape[:2]
+        if h == 0 or w == 0:
+            raise ValueError("empty image")
         if max(h, w) <= config.MAX_IMAGE_HEIGHT_AND_WIDTH:
             return np.ascontiguousarray(a)
         image = Image.fromarray(a)
@@ -373,7 +375,11 @@ class RegionEmbedder:
             if getattr(self, "_rows_as_array", False):
                 rows = list(pipe["out"][slot][:n].numpy().copy())  # float32 row views (get_image_embeddings(as_array=True))
             else:
-                rows = pipe["out"][slot][:n].tolist()  # embedder.py:132 `.cpu().tolist()`
+                # embedder.py:132 `.cpu().tolist()`.  In slices: one tolist() of a whole group holds the GIL for tens of
+                # milliseconds, during which the producer thread cannot even start its next (GIL-free) buffer copy
+                buf, rows = pipe["out"][slot], []
+                for c0 in range(0, n, 64):
+                    rows.extend(buf[c0 : min(n, c0 + 64)].tolist())
             results.extend(zip(idx, rows))
 
         producer = threading.Thread(target=produce, name=f"mme-stage-{dev_idx}", daemon=True)
