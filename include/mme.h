@@ -111,6 +111,22 @@ int mme_set_gemm_variant(mme_ctx* ctx, int variant);
  *   0 separate LayerNorm kernel (A/B, tests). */
 int mme_set_ln_fusion(mme_ctx* ctx, int mode);
 
+/* K5 (attention of the ViT-B/16 forward, transformers modeling_vit.py:164-189).
+ *   1 (default) fast form: the exponentials of a query row are taken against the maximum over its first 32 keys instead
+ *     of its row maximum -- softmax is invariant to that choice, only the range differs -- which lets the scores leave
+ *     the matrix pipe ready for exp2.  A row whose sum leaves [1, 2^100) raises a per-launch guard word and the
+ *     launch is redone by the exact kernel (the decision is taken on the device; the call stays asynchronous), so
+ *     every finite input gets the exact algorithm's result;
+ *   0 exact form only (row maximum first), as the reference computes it.
+ *   2 the fast form with the guard forced for every row: every launch is redone by the exact kernel (a test of the
+ *     re-run path: outputs are bit-identical to mode 0).
+ * Outputs of modes 0 and 1 agree to rounding (different rounding points of the probabilities), not bit for bit.
+ * The query projection carries dh^-0.5 log2(e) in every mode (folded into W_q / b_q by mme_load_vit). */
+int mme_set_attention_mode(mme_ctx* ctx, int mode);
+/* Diagnostic (synchronises the device): flags[l] != 0 when the attention launch of layer l of the LAST encoder pass
+ * raised its guard and was redone by the exact kernel. */
+int mme_attention_redone(mme_ctx* ctx, int32_t flags[12]);
+
 /* ---- K0: cut the bounding boxes of one decoded page on the device ----------
  * Replaces DocLayoutDetector.get_region_image (doclayout_detector.py:165-194), which re-opens
  * and re-decodes the whole page PNG for every region: the page is uploaded once and every box

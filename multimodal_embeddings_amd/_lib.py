@@ -72,6 +72,8 @@ EXPORTS = {
     "mme_set_chunk": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_set_gemm_variant": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_set_ln_fusion": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_set_attention_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_attention_redone": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mme_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -280,6 +282,17 @@ class Engine:
         """0 / False: LayerNorm kernel; 1: folded + statistics pass over x; 2 / True: folded + partial sums from the producing GEMM."""
         m = 2 if mode is True else int(mode)
         self._check(self.lib.mme_set_ln_fusion(self.h, m), "mme_set_ln_fusion")
+
+    def set_attention_mode(self, mode):
+        """1 / "fast" (default): guarded fast softmax; 0 / "exact": row maximum first (see mme.h)."""
+        m = {"exact": 0, "fast": 1, "fast_forced_redo": 2}.get(mode, mode)
+        self._check(self.lib.mme_set_attention_mode(self.h, int(m)), "mme_set_attention_mode")
+
+    def attention_redone(self):
+        """Layers of the LAST encoder pass whose attention launch raised the fast form's guard (list of 12 ints)."""
+        flags = (C.c_int32 * 12)()
+        self._check(self.lib.mme_attention_redone(self.h, flags), "mme_attention_redone")
+        return list(flags)
 
     def set_chunk(self, crops: int):
         self._check(self.lib.mme_set_chunk(self.h, int(crops)), "mme_set_chunk")

@@ -138,6 +138,7 @@ int ensure_workspace(mme_ctx* c) {
     if ((r = ensure(c, c->mlp, rows * VIT_F * 2))) return r;
     if ((r = ensure(c, c->stats, rows * 2 * sizeof(float)))) return r;
     if ((r = ensure(c, c->lnpart, rows * 2 * (VIT_D / 64) * sizeof(float)))) return r;
+    if ((r = ensure(c, c->attn_guard, 64 * sizeof(int)))) return r;
     c->ws_chunk = c->chunk;
     return MME_OK;
 }
@@ -197,6 +198,8 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
         Timed t(c, s, KC_LN);
         HIP_TRY(c, launch_cls_rows(c->x.p, c->cls, c->pos, n, s));
     }
+    // one guard word per layer for the attention kernel's fast form (attention.hip): zero = no row left its range
+    if (c->attn_mode) HIP_TRY(c, hipMemsetAsync(c->attn_guard.p, 0, 64 * sizeof(int), s));
     // LayerNorm statistics of the residual stream x for the GEMM that folds the LayerNorm in.  Mode 2: the GEMM
     // that WROTE x (EPI_BIAS_RES_STATS) left per-slice partial sums; finishing them reads 96 bytes per row
     // instead of the 1536-byte row.  Rows of a ragged last row tile, launches that ran the 128 x 128 kernel and
@@ -239,7 +242,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
         }
         {
             Timed t(c, s, KC_ATTN);
-            HIP_TRY(c, launch_attention(c->qkv.p, c->att.p, n, s));
+            HIP_TRY(c, launch_attention(c->qkv.p, c->att.p, n, s, c->attn_mode ? (int*)c->attn_guard.p + l : nullptr, c->attn_mode == 2));
         }
         {
             Timed t(c, s, KC_GEMM);
@@ -442,7 +445,7 @@ void mme_destroy(mme_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
-    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->htab, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws, &c->zero_bias};
+    DevBuf* bufs[] = {&c->x, &c->hbuf, &c->qkv, &c->att, &c->mlp, &c->patches, &c->tmp, &c->htab, &c->crops, &c->hwork, &c->page_ws, &c->cluster_ws, &c->stats, &c->lnpart, &c->neigh_ws, &c->zero_bias, &c->attn_guard};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->lut) (void)hipFree(c->lut);
@@ -488,10 +491,17 @@ int mme_load_vit(mme_ctx* c, const mme_vit_weights* w) {
         if ((r = upload_f32(c, a.ln1_b, VIT_D, &L.ln1_b))) return r;
         if ((r = upload_f32(c, a.ln2_g, VIT_D, &L.ln2_g))) return r;
         if ((r = upload_f32(c, a.ln2_b, VIT_D, &L.ln2_b))) return r;
-        const float* qkv[3] = {a.q_w, a.k_w, a.v_w};
+        // The attention kernel takes its scores in log2 units straight from the matrix pipe (attention.hip, PRESCALED):
+        // dh^-0.5 * log2(e) is folded into the query projection here, once, BEFORE the rounding to bf16 that the upload
+        // applies anyway -- softmax(q.k / 8) = exp2(q'.k - c) / sum with q' = (W_q' x + b_q'), W_q' = sc W_q, b_q' = sc b_q.
+        const float sc = 0.125f * 1.44269504088896341f;
+        std::vector<float> qw_s((size_t)VIT_D * VIT_D), qb_s(VIT_D);
+        for (size_t i = 0; i < qw_s.size(); ++i) qw_s[i] = a.q_w[i] * sc;
+        for (int i = 0; i < VIT_D; ++i) qb_s[i] = a.q_b[i] * sc;
+        const float* qkv[3] = {qw_s.data(), a.k_w, a.v_w};
         const size_t r3[3] = {VIT_D, VIT_D, VIT_D};
         if ((r = upload_bf16(c, qkv, r3, 3, VIT_D, &L.qkv_w))) return r;
-        const float* qkvb[3] = {a.q_b, a.k_b, a.v_b};
+        const float* qkvb[3] = {qb_s.data(), a.k_b, a.v_b};
         if ((r = upload_f32_cat(c, qkvb, r3, 3, &L.qkv_b))) return r;
         if ((r = upload_folded(c, qkv, qkvb, r3, 3, VIT_D, a.ln1_g, a.ln1_b, &L.qkv_wf, &L.qkv_cs, &L.qkv_bf))) return r;
         const float* o[1] = {a.o_w};
@@ -534,6 +544,23 @@ int mme_set_ln_fusion(mme_ctx* c, int mode) {
     if (!c) return MME_E_ARG;
     if (mode < 0 || mode > 2) return fail(c, MME_E_ARG, "mme_set_ln_fusion: 0 (LayerNorm kernel), 1 (folded, statistics pass over x) or 2 (folded, partial sums from the producing GEMM)");
     c->ln_mode = mode;
+    return MME_OK;
+}
+
+int mme_set_attention_mode(mme_ctx* c, int mode) {
+    if (!c) return MME_E_ARG;
+    if (mode < 0 || mode > 2) return fail(c, MME_E_ARG, "mme_set_attention_mode: 0 (exact row maximum), 1 (fast form, guarded; the default) or 2 (fast form with the guard forced: every launch is redone exactly)");
+    c->attn_mode = mode;
+    return MME_OK;
+}
+
+int mme_attention_redone(mme_ctx* c, int32_t flags[12]) {
+    if (!c || !flags) return fail(c, MME_E_ARG, "mme_attention_redone: null argument");
+    for (int l = 0; l < VIT_L; ++l) flags[l] = 0;
+    if (!c->attn_guard.p) return MME_OK;  // no pass has run yet
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    HIP_TRY(c, hipMemcpy(flags, c->attn_guard.p, VIT_L * sizeof(int32_t), hipMemcpyDeviceToHost));
     return MME_OK;
 }
 
@@ -1126,11 +1153,12 @@ int mme_attention_stamps(mme_ctx* c, int B, int iters, double* avg_ms, uint64_t*
     if (!c || !avg_ms || !stamps_host || B <= 0 || iters < 1) return fail(c, MME_E_ARG, "mme_attention_stamps: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t rows = (size_t)B * VIT_T, q_bytes = rows * 3 * VIT_D * 2, o_bytes = rows * VIT_D * 2, st_bytes = (size_t)B * 64 * sizeof(uint64_t);
-    void *Q = nullptr, *O = nullptr, *ST = nullptr;
+    void *Q = nullptr, *O = nullptr, *ST = nullptr, *G = nullptr;
     int rc = MME_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     do {
-        if (hipMalloc(&Q, q_bytes) != hipSuccess || hipMalloc(&O, o_bytes) != hipSuccess || hipMalloc(&ST, st_bytes) != hipSuccess) { rc = fail(c, MME_E_NOMEM, "mme_attention_stamps: hipMalloc"); break; }
+        if (hipMalloc(&Q, q_bytes) != hipSuccess || hipMalloc(&O, o_bytes) != hipSuccess || hipMalloc(&ST, st_bytes) != hipSuccess || hipMalloc(&G, 256) != hipSuccess) { rc = fail(c, MME_E_NOMEM, "mme_attention_stamps: hipMalloc"); break; }
+        (void)hipMemset(G, 0, 256);
         {   // uniform [-1, 1) bf16 activations, a 64 MB pattern repeated
             const size_t pat = (size_t)32 << 20;
             std::vector<uint16_t> h(pat);
@@ -1144,10 +1172,10 @@ int mme_attention_stamps(mme_ctx* c, int B, int iters, double* avg_ms, uint64_t*
             if (rc) break;
         }
         hipStream_t s = nullptr;
-        if (launch_attention(Q, O, B, s) != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_attention_stamps: launch"); break; }
+        if (launch_attention(Q, O, B, s, (int*)G) != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_attention_stamps: launch"); break; }
         (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         (void)hipEventRecord(e0, s);
-        for (int i = 0; i < iters; ++i) (void)launch_attention(Q, O, B, s);
+        for (int i = 0; i < iters; ++i) (void)launch_attention(Q, O, B, s, (int*)G);
         (void)hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(c, MME_E_HIP, "mme_attention_stamps: kernel failed"); break; }
         float ms = 0.f;
@@ -1159,7 +1187,7 @@ int mme_attention_stamps(mme_ctx* c, int B, int iters, double* avg_ms, uint64_t*
     } while (0);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    for (void* p : {Q, O, ST}) if (p) (void)hipFree(p);
+    for (void* p : {Q, O, ST, G}) if (p) (void)hipFree(p);
     return rc;
 }
 

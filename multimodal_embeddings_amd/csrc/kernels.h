@@ -75,7 +75,9 @@ hipError_t launch_pool(const void* x, const float* gamma, const float* beta, int
 // f32 [rows,d] -> L2-normalised bf16 [rows,d]
 hipError_t launch_normalise_rows(const float* x, int64_t rows, int d, void* y, hipStream_t s);
 // fused multi-head attention, T=197, dh=64, 12 heads; qkv [B*197, 2304] -> out [B*197, 768]
-hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s);
+// guard: device int, zero before the launch; non-null selects the FAST kernel + the conditional exact re-run (attention.hip)
+// force_redo: the fast kernel raises the guard for every row (test of the re-run path)
+hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard = nullptr, bool force_redo = false);
 // diagnostic: stamped build, stamps uint64[B][8][8]
 hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s);
 

@@ -181,6 +181,52 @@ def test_embed_hot_weights(engine_hot, golden_dir):
     _check_embeddings(e32.cpu().numpy(), want)
 
 
+def test_attention_fast_form_guard_and_exact_rerun(engine, golden_dir):
+    """K5's default form takes the exponentials of a query row against the maximum over its FIRST 32 keys (softmax is
+    invariant to the reference point); a row whose sum leaves [1, 2^100) raises a guard word and the launch is redone
+    by the exact kernel.  (1) fast and exact agree to rounding and both meet the oracle; no layer is redone on ordinary
+    inputs; (2) with the guard forced (mode 2) every layer is redone and the result is the exact kernel's bit for bit;
+    (3) query / key weights scaled so that scores spread over hundreds of log2 units trip the guard for real: finite
+    outputs, the redone layers flagged, and the result is the exact kernel's (bit for bit when every layer was redone,
+    to rounding otherwise; no oracle bar here: at such scores the bf16 rounding of Q and K alone moves an arg-max)."""
+    from multimodal_embeddings_amd._lib import Engine
+
+    arrays, _ = _golden_crops(golden_dir)
+    arrays = arrays[:12]
+    pix, offs, hw = _pack(arrays)
+    w = make_vit_weights(seed=1)
+    want = _oracle_embed(arrays, w, "cls")
+    engine.set_attention_mode("exact")
+    exact, _ = engine.embed(pix, offs, hw)
+    assert engine.attention_redone() == [0] * 12
+    engine.set_attention_mode("fast")
+    fast, _ = engine.embed(pix, offs, hw)
+    assert engine.attention_redone() == [0] * 12
+    engine.set_attention_mode("fast_forced_redo")
+    forced, _ = engine.embed(pix, offs, hw)
+    assert engine.attention_redone() == [1] * 12
+    engine.set_attention_mode("fast")
+    _check_embeddings(exact.cpu().numpy(), want)
+    _check_embeddings(fast.cpu().numpy(), want)
+    assert torch.equal(forced, exact)
+    assert float((1.0 - (fast * exact).sum(dim=1)).max()) <= 1e-4
+    # (3) scores far outside the range a tile-0 reference point covers
+    wild = {k: (v * 16.0 if (".q_proj.weight" in k or ".k_proj.weight" in k) else v) for k, v in w.items()}
+    assert any(not np.array_equal(wild[k], w[k]) for k in w), sorted(w)[:8]
+    e = Engine(0)
+    e.load_vit(wild)
+    got, _ = e.embed(pix, offs, hw)
+    redone = e.attention_redone()
+    e.set_attention_mode("exact")
+    ref, _ = e.embed(pix, offs, hw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and torch.isfinite(ref).all() and sum(redone) >= 1, redone
+    assert float((1.0 - (got * ref).sum(dim=1)).max()) <= 1e-3, redone
+    if all(redone):
+        assert torch.equal(got, ref)
+    e.close()
+
+
 def test_embed_matches_transformers_golden(engine, golden_dir):
     """vit_cases.npz was produced by transformers.ViTModel itself (make_golden.py)."""
     g = np.load(os.path.join(golden_dir, "vit_cases.npz"))

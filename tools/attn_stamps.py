@@ -18,10 +18,17 @@ NAMES = ["wait own", "barrier", "issue next", "S^T", "softmax", "P.V", "handover
 def main():
     eng = Engine(0)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    for dbg in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]:
-        os.environ["MME_ATTN_DEBUG"] = str(dbg)
-        print(f"--- MME_ATTN_DEBUG={dbg} (stamped build only: 1 no K re-reads, 2 no K/V requests after head 0, 4 no max, 8 no exp)")
-        report(eng, B)
+    shares = [v for v in (sys.argv[4].split(",") if len(sys.argv) > 4 else [""])]
+    for pipe, share in [(int(v), sh) for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["1", "2"]) for sh in shares]:
+        os.environ["MME_ATTN_PIPE"] = str(pipe)
+        if share != "":
+            os.environ["MME_ATTN_SHARE"] = share
+            print(f"=== K/V pieces requested by each computing wave: {share}")
+        for dbg in [int(v) for v in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0"])]:
+            os.environ["MME_ATTN_DEBUG"] = str(dbg)
+            print(f"--- kernel form {pipe} (1 exact row maximum, 2 fast / reference point from key tile 0); MME_ATTN_DEBUG={dbg} "
+                  "(exact stamped build only: 1 no K re-reads, 2 no K/V requests after head 0, 4 no max, 8 no exp)")
+            report(eng, B)
 
 
 def report(eng, B):
