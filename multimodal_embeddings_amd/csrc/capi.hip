@@ -192,8 +192,13 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
         g.pos = c->pos;
         g.out = c->x.p;
         g.ldo = VIT_D;
+        if (c->ln_mode == 2) {  // the 256 x 256 kernel leaves the LayerNorm partial sums of the token rows it writes
+            g.ln_part = (float*)c->lnpart.p;
+            g.ln_part_rows = (int64_t)c->ws_chunk * VIT_T;
+        }
         HIP_TRY(c, launch_gemm(EPI_PATCH, g, s, c->gemm_variant));
     }
+    const GemmArgs patch_args = g;
     {
         Timed t(c, s, KC_LN);
         HIP_TRY(c, launch_cls_rows(c->x.p, c->cls, c->pos, n, s));
@@ -220,7 +225,19 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
     };
     const int res_epi = c->ln_mode == 2 ? EPI_BIAS_RES_STATS : EPI_BIAS_RES;
     int r;
-    if (c->ln_mode != 0 && (r = stats_from_x(0))) return r;
+    if (c->ln_mode == 2 && gemm_runs_256(patch_args, c->gemm_variant)) {
+        // first LayerNorm of the pass: the patch-embed epilogue left the partial sums of every token row an INTERIOR tile
+        // wrote (patch rows [0, interior) -> token rows up to t_int); the [CLS] rows (written by cls_rows, every 197th
+        // row) and the rows of the ragged last tile take the stand-alone kernel, same canonical order
+        const int64_t interior = (int64_t)(patch_args.M / 256) * 256;                      // patch rows
+        const int64_t t_int = interior ? interior - 1 + (interior - 1) / VIT_NP + 2 : 0;   // one past the last token row they map to
+        Timed t(c, s, KC_LN);
+        HIP_TRY(c, launch_ln_finish((const float*)c->lnpart.p, patch_args.ln_part_rows, t_int, VIT_D, c->ln_eps, (float*)c->stats.p, s));
+        HIP_TRY(c, launch_ln_stats_canonical(c->x.p, 0, t_int, VIT_D, c->ln_eps, (float*)c->stats.p, s, VIT_T));  // [CLS] rows below t_int
+        HIP_TRY(c, launch_ln_stats_canonical(c->x.p, t_int, M, VIT_D, c->ln_eps, (float*)c->stats.p, s));
+    } else if (c->ln_mode != 0 && (r = stats_from_x(0))) {
+        return r;
+    }
     for (int l = 0; l < VIT_L; ++l) {
         const LayerDev& L = c->layer[l];
         if (c->ln_mode != 0) {  // LN1 folded into the QKV GEMM: x is read once, nothing normalised is written

@@ -338,29 +338,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
             // interior tile: straight-line code, no per-lane predicate (a branch would make the
             // compiler re-insert vmcnt(0) -- i.e. a wait for the stores -- at every join)
             if constexpr (EPI == EPI_PATCH) {
-                const int nb = n0 + wn * 64 + fq * 4;
-                const int mb = m0 + wm * 128 + fr;
-                f32x4 bv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nb + j * 16);
-#pragma unroll
-                for (int i0 = 0; i0 < 8; i0 += 2) {
-                    EpiRow er[2];
-                    f32x4 pv[2][4];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        er[i] = epi_row<EPI>(mb + (i0 + i) * 16);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) pv[i][j] = *(const f32x4*)(g.pos + (int64_t)er[i].prow * g.N + nb + j * 16);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const f32x4 v = acc[i0 + i][j] + bv[j] + pv[i][j];
-                            *(uint2*)((bf16_t*)g.out + er[i].orow * g.ldo + nb + j * 16) = pack_bf16x4(v);
-                        }
-                }
+                epilogue_wave_patch_128x64(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {});
             } else {
                 if constexpr (DEFER && epi_has_fast_path<EPI>()) {
                     epilogue_wave_128x64<EPI, NDEF>(g, acc, m0 + wm * 128, n0 + wn * 64, fr, fq, [] {}, pend);

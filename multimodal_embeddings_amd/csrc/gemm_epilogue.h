@@ -5,6 +5,8 @@
 // position vectors load as one 16- or 8-byte vector and the result stores as bf16x4 (8 B) or
 // f32x4 (16 B).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -261,6 +263,114 @@ __device__ __forceinline__ void epilogue_wave_128x64(const GemmArgs& g, f32x4 (&
         float* plane = g.ln_part + ((int64_t)(fq & 1) * (g.N >> 6) + (nw >> 6)) * g.ln_part_rows + mw + (fq >> 1) * 16 + fr;
 #pragma unroll
         for (int k = 0; k < 4; ++k) plane[k * 32] = u[k];
+    }
+}
+
+// Interior-tile epilogue of one wave tile of the PATCH-EMBED GEMM (EPI_PATCH): row m = (crop b, patch p) of the im2col
+// matrix goes to token row b * 197 + 1 + p of the residual stream, + bias[n] + pos[1 + p, n] (f32), rounded to bf16.
+// Same rules as epilogue_wave_128x64 -- 16-byte stores built with v_permlane16_swap, loads never behind stores -- with
+// two differences: (1) the position rows are f32 and per lane (a 128-row wave tile crosses at most one crop boundary:
+// 196 > 128), 32 x 16 bytes per lane, more registers than the accumulators leave free, so they are fetched in two
+// halves: the loads of row blocks 4..7 are ISSUED before the stores of row blocks 0..3 (vmcnt retires in order and
+// counts stores: waiting for those loads then leaves exactly the eight stores in flight); (2) when g.ln_part is set
+// the LayerNorm partial sums of the rounded outputs are left per OUTPUT row in the canonical order (ln_accumulate),
+// so that the first LayerNorm of the pass needs no pass over x (the [CLS] rows, written by cls_rows, and the rows of
+// a ragged last tile get theirs from ln_stats_canonical_rows).
+template <class Between>
+__device__ __forceinline__ void epilogue_wave_patch_128x64(const GemmArgs& g, f32x4 (&acc)[8][4], int mw, int nw, int fr, int fq, Between&& between) {
+    const int b0 = mw / VIT_NP;                                  // wave-uniform: crop of the tile's first row
+    const int64_t orow0 = (int64_t)mw + b0 + 1;                  // its token row
+    bf16_t* outb = (bf16_t*)g.out + orow0 * g.ldo + nw;          // wave-uniform base; lane offsets fit 32 bits
+    const int c0 = row16_col(0, fq), c1 = row16_col(2, fq);
+    f32x4 bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = *(const f32x4*)(g.bias + nw + fq * 4 + j * 16);
+    // per row block i: does this lane's row lie in the NEXT crop (bit i)?  Output row and position row follow from it.
+    const int first_next = (b0 + 1) * VIT_NP - mw - fr;  // rows with 16 i >= first_next belong to crop b0 + 1
+    const int lo_base = fr * (int)g.ldo, po_base = (mw - b0 * VIT_NP + 1 + fr) * g.N + nw + fq * 4;
+    auto lo_of = [&](int i) { return lo_base + (i * 16 + (i * 16 >= first_next ? 1 : 0)) * (int)g.ldo; };
+    auto po_of = [&](int i) { return po_base + (i * 16 - (i * 16 >= first_next ? VIT_NP : 0)) * g.N; };
+    const bool stats = g.ln_part != nullptr;  // wave-uniform
+    float psum[8], psq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) psum[i] = psq[i] = 0.f;
+    // quarters of two row blocks: the position rows of quarter k + 1 are requested before the stores of quarter k
+    f32x4 pv[2][2][4];
+    uint4 packed[2][2];
+    auto load_pos = [&](auto k_tag) {
+        constexpr int K = decltype(k_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pv[K & 1][i][j] = *(const f32x4*)(g.pos + po_of(2 * K + i) + j * 16);
+    };
+    auto compute = [&](auto k_tag) {
+        constexpr int K = decltype(k_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jp = 0; jp < 4; jp += 2) {
+                const uint2 pk0 = pack_bf16x4(acc[2 * K + i][jp] + bv[jp] + pv[K & 1][i][jp]);
+                const uint2 pk1 = pack_bf16x4(acc[2 * K + i][jp + 1] + bv[jp + 1] + pv[K & 1][i][jp + 1]);
+                ln_accumulate(pk0, psum[2 * K + i], psq[2 * K + i]);  // canonical order: column tiles ascending, pairs in order
+                ln_accumulate(pk1, psum[2 * K + i], psq[2 * K + i]);
+                packed[i][jp >> 1] = pair_to_row16(pk0, pk1);
+            }
+    };
+    auto store = [&](auto k_tag) {
+        constexpr int K = decltype(k_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(outb + lo_of(2 * K + i) + c0) = packed[i][0];
+            *(uint4*)(outb + lo_of(2 * K + i) + c1) = packed[i][1];
+        }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    load_pos(K0{});
+    load_pos(K1{});
+    asm volatile("" ::: "memory");
+    between();
+    asm volatile("" ::: "memory");
+    compute(K0{});
+    asm volatile("" ::: "memory");
+    store(K0{});
+    asm volatile("" ::: "memory");
+    compute(K1{});
+    load_pos(K2{});  // into the registers quarter 0 has left, BEFORE quarter 1's stores
+    asm volatile("" ::: "memory");
+    store(K1{});
+    asm volatile("" ::: "memory");
+    compute(K2{});
+    load_pos(K3{});
+    asm volatile("" ::: "memory");
+    store(K2{});
+    asm volatile("" ::: "memory");
+    compute(K3{});
+    store(K3{});
+    if (stats) {
+        // as EPI_BIAS_RES_STATS: totals over the four lanes (fq) that share a row, ((fq0 + fq1) + (fq2 + fq3))
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(psum[k]), __float_as_uint(psq[k]), false, false);
+            t[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        float u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[2 * k]), __float_as_uint(t[2 * k + 1]), false, false);
+            u[k] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        }
+        // lane (fq, fr) holds, for k = 0..3, plane (fq & 1) of patch row mw + (fq >> 1) * 16 + fr + 32 k
+        float* plane = g.ln_part + ((int64_t)(fq & 1) * (g.N >> 6) + (nw >> 6)) * g.ln_part_rows;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int m = mw + (fq >> 1) * 16 + fr + 32 * k;
+            plane[(int64_t)m + m / VIT_NP + 1] = u[k];
+        }
     }
 }
 

@@ -62,7 +62,8 @@ hipError_t launch_layernorm(const void* x, const float* gamma, const float* beta
 hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats, hipStream_t s);
 // the same statistics in the CANONICAL summation order shared with the EPI_BIAS_RES_STATS epilogue, for rows
 // [row0, row1) of bf16 rows of `d` (d % 64 == 0, d <= 2048): one pass over x
-hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s);
+// rows row0, row0 + stride, ... < row1
+hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s, int64_t stride = 1);
 // finishes rows [0, rows) from the partial planes an EPI_BIAS_RES_STATS GEMM left: part [2][d/64][part_rows]
 hipError_t launch_ln_finish(const float* part, int64_t part_rows, int64_t rows, int d, float eps, float* stats, hipStream_t s);
 // true when launch_gemm(variant) runs the 256 x 256 kernel (whose fast-path epilogue writes the partial planes)

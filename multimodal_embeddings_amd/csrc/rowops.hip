@@ -83,9 +83,9 @@ __global__ __launch_bounds__(256) void ln_stats_rows(const bf16_t* __restrict__ 
 // EPI_BIAS_RES_STATS epilogue produced the partial sums: the first LayerNorm of a pass, small problems that run
 // the 128 x 128 kernel, the rows of a ragged last row tile.
 __global__ __launch_bounds__(256) void ln_stats_canonical_rows(const bf16_t* __restrict__ x, int64_t row0, int64_t row1, int d, float eps,
-                                                               float* __restrict__ stats) {
+                                                               float* __restrict__ stats, int64_t stride) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = row0 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = row0 + ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * stride;  // rows row0, row0 + stride, ... < row1
     if (row >= row1) return;
     const int slice = lane >> 2, grp = lane & 3, nslice = d >> 6;  // a lane serves slices `slice` and `slice + 16` (d <= 2048)
     float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};
@@ -248,11 +248,12 @@ hipError_t launch_ln_stats(const void* x, int64_t rows, float eps, float* stats,
     return hipGetLastError();
 }
 
-hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s) {
+hipError_t launch_ln_stats_canonical(const void* x, int64_t row0, int64_t row1, int d, float eps, float* stats, hipStream_t s, int64_t stride) {
     if (row1 <= row0) return hipSuccess;
-    if (d <= 0 || (d % 64) != 0 || d > 2048) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_stats_canonical_rows, dim3((unsigned)((row1 - row0 + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, row0, row1, d, eps,
-                       stats);
+    if (d <= 0 || (d % 64) != 0 || d > 2048 || stride < 1) return hipErrorInvalidValue;
+    const int64_t nrows = (row1 - row0 + stride - 1) / stride;
+    hipLaunchKernelGGL(ln_stats_canonical_rows, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, s, (const bf16_t*)x, row0, row1, d, eps,
+                       stats, stride);
     return hipGetLastError();
 }
 
