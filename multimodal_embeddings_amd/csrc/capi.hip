@@ -175,6 +175,36 @@ int set_lut(mme_ctx* c, const float mean[3], const float stdv[3]) {
         c->lut = (float*)p;
     }
     HIP_TRY(c, hipMemcpy(c->lut, h, sizeof h, hipMemcpyHostToDevice));
+    // The patch emitter rounds the table value to bf16.  Look for (a, b) per channel with bf16(fma(u, a, b)) == bf16(table[u])
+    // for ALL 256 u: start from the f64-rounded slope / offset and try the f32 neighbours (a few ulps each way).  Found for
+    // the CLIP and the 0.5 / 0.5 constants; when not, the kernel keeps reading the table (exact = 0).
+    NormAffine aff{};
+    aff.exact = 1;
+    for (int ch = 0; ch < 3 && aff.exact; ++ch) {
+        const float a0 = (float)((1.0 / 255.0) / (double)stdv[ch]), b0 = (float)(-(double)mean[ch] / (double)stdv[ch]);
+        bool found = false;
+        for (int da = 0; da <= 8 && !found; ++da)
+            for (int sa = -1; sa <= 1 && !found; sa += 2) {
+                if (da == 0 && sa == 1) continue;
+                float a = a0;
+                for (int k = 0; k < da; ++k) a = std::nextafterf(a, sa < 0 ? -INFINITY : INFINITY);
+                for (int db = 0; db <= 8 && !found; ++db)
+                    for (int sb = -1; sb <= 1 && !found; sb += 2) {
+                        if (db == 0 && sb == 1) continue;
+                        float b = b0;
+                        for (int k = 0; k < db; ++k) b = std::nextafterf(b, sb < 0 ? -INFINITY : INFINITY);
+                        bool ok = true;
+                        for (int u = 0; u < 256 && ok; ++u) ok = f32_to_bf16_rne(std::fmaf((float)u, a, b)) == f32_to_bf16_rne(h[ch * 256 + u]);
+                        if (ok) {
+                            aff.a[ch] = a;
+                            aff.b[ch] = b;
+                            found = true;
+                        }
+                    }
+            }
+        if (!found) aff.exact = 0;
+    }
+    c->norm_aff = aff;
     return MME_OK;
 }
 
@@ -409,7 +439,9 @@ int preprocess_chunk(mme_ctx* c, const uint8_t* pix, const int64_t* offs, const 
     if ((r = run_h_pass(c, plan, pix, n, s, "mme_preprocess"))) return r;
     Timed t(c, s, KC_PRE);
     if ((r = launch_h_pass(c, plan, pix, n, s, "mme_preprocess"))) return r;
-    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, patches, any_resize,
+    NormAffine aff = c->norm_aff;
+    if (diag_env("MME_K1_TABLE")) aff.exact = 0;  // A/B (diagnostic build): the table form of the patch emitter
+    HIP_TRY(c, launch_resize_v_patchify(pix, (const uint8_t*)c->tmp.p, (const CropDesc*)c->crops.p, n, c->lut, aff, patches, any_resize,
                                         (const uint8_t*)c->htab.p, plan.kv_max, s));
     return MME_OK;
 }

@@ -49,6 +49,7 @@ struct mme_ctx {
     bf16_t* patch_w = nullptr;
     LayerDev layer[VIT_L];
     float* lut = nullptr;  // [3,256]
+    NormAffine norm_aff{};  // the same mapping as one fma per value where that is bit-exact after the bf16 rounding (set_lut)
     // workspace (sized for `chunk` crops)
     int ws_chunk = 0;
     DevBuf attn_guard;      // int[64]: one guard word per layer of a pass (attention.hip, FAST form)

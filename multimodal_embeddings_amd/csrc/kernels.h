@@ -135,8 +135,17 @@ hipError_t launch_resize_v_tiles(const uint8_t* pix, const uint8_t* tmp, const C
 // K0: boxes int32[n,4] (x0,y0,x1,y1), offs int64[n] byte offsets into pix; zero fill outside the page
 hipError_t launch_crop_boxes(const uint8_t* page, int H, int W, const int32_t* boxes, const int64_t* offs, const HWork* work, int nwork,
                              uint8_t* pix, hipStream_t s);
+// bf16(lut[c][u]) == bf16(fma(u, a[c], b[c])) for all 256 u and the 3 channels, VERIFIED on the host when the table was
+// built (capi.hip, set_lut): the patch emitter then computes the value instead of reading the table at 64 data-dependent
+// LDS addresses per instruction (47 % of that kernel's LDS cycles were bank conflicts, profiles/round2_pmc_k1_sq.csv).
+// exact == 0: no such pair was found for this mean / std -- the emitter keeps the table.
+struct NormAffine {
+    float a[3], b[3];
+    int exact;
+};
 hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n,
-                                    const float* lut /*[3,256]*/, void* patches, bool any_resize, const uint8_t* tab, int kv_max, hipStream_t s);
+                                    const float* lut /*[3,256]*/, const NormAffine& aff, void* patches, bool any_resize, const uint8_t* tab, int kv_max,
+                                    hipStream_t s);
 
 // K13: class-aware greedy NMS, one workgroup per page (3_combine_grids.py:80-137).  boxes f64[n,4] (x0,y0,x1,y1),
 // page p owns boxes [page_offs[p], page_offs[p+1]); order int32[n] is scratch; keep int32[n] receives, per page, the

@@ -273,7 +273,7 @@ template <bool RESIZE>
 __global__ __launch_bounds__(RESIZE ? 512 : 256, RESIZE ? 8 : 1) void resize_v_patchify(const uint8_t* __restrict__ pix, const uint8_t* __restrict__ tmp,
                                                          const CropDesc* __restrict__ crops, const float* __restrict__ lut,
                                                          bf16_t* __restrict__ patches, const uint8_t* __restrict__ tab, int window_bytes,
-                                                         int kvs) {
+                                                         int kvs, const NormAffine aff) {
     constexpr int NT = RESIZE ? 512 : 256;
     constexpr int ROW = VIT_IMG * 3, ROW4 = ROW / 4, NIT = (VIT_PATCH * ROW4 + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) uint8_t canvas[VIT_PATCH * ROW + 16];
@@ -309,7 +309,9 @@ __global__ __launch_bounds__(RESIZE ? 512 : 256, RESIZE ? 8 : 1) void resize_v_p
         rows_chunk = max(window_bytes / pitch, 1);
         dma_range_to_lds<NT>((const uint4*)(src + (int64_t)r0 * pitch), (char*)window, (min(r0 + rows_chunk, r1) - r0) * (pitch >> 4), tid);
     }
-    for (int i = tid; i < 768; i += NT) slut[i] = lut[i];
+    const bool affine = RESIZE && aff.exact;  // the all-224 x 224 instantiation is an HBM-bound stream: its table form measured 5 % faster (tools/k1_ab.py)
+    if (!affine)
+        for (int i = tid; i < 768; i += NT) slut[i] = lut[i];
     if (nout > 0) {
         if (vpass) {  // this band's 16 windows and coefficient rows from the crop's table
             const K1Layout L = k1_layout(c.h, c.w, c.new_h, c.new_w);
@@ -398,8 +400,34 @@ __global__ __launch_bounds__(RESIZE ? 512 : 256, RESIZE ? 8 : 1) void resize_v_p
         }
     }
     __syncthreads();
-    // 14 patches x 768 values; a thread emits 8 consecutive kx of one (patch, c, ky)
+    // 14 patches x 768 values (im2col order (c, ky, kx))
     bf16_t* out = patches + ((int64_t)crop * VIT_NP + py * VIT_GRID) * VIT_D;
+    if (affine) {
+        // A thread emits 8 consecutive kx of one (patch, ky) for ALL three channels: 24 contiguous canvas bytes (8-byte
+        // aligned: (16 px + 8 half) * 3) as three 8-byte LDS reads, every byte converted in place (v_cvt_f32_ubyteN) and
+        // normalised by one fma -- verified bit-exact against the table after the bf16 rounding (NormAffine) -- then three
+        // 16-byte stores, one per channel plane of the patch row.  (The table form below reads the canvas byte by byte
+        // and the table at 64 data-dependent addresses: 47 % of the LDS cycles were bank conflicts.)
+        for (int e = tid; e < VIT_GRID * VIT_PATCH * 2; e += NT) {
+            const int px = e >> 5, ky = (e >> 1) & 15, kx0 = (e & 1) * 8;
+            const uint2* cp = (const uint2*)(canvas + ky * ROW + (px * VIT_PATCH + kx0) * 3);
+            const uint2 w0 = cp[0], w1 = cp[1], w2 = cp[2];
+            const uint32_t w[6] = {w0.x, w0.y, w1.x, w1.y, w2.x, w2.y};
+            bf16x8 o[3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const int byte = j * 3 + ch;
+                    const float v = (float)((w[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                    o[ch][j] = (bf16_t)fmaf(v, aff.a[ch], aff.b[ch]);
+                }
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) *(bf16x8*)(out + (int64_t)px * VIT_D + ch * 256 + ky * 16 + kx0) = o[ch];
+        }
+        return;
+    }
+    // table form: a thread emits 8 consecutive kx of one (patch, c, ky)
     for (int e = tid; e < VIT_GRID * VIT_D / 8; e += NT) {
         const int px = e / (VIT_D / 8), q = e - px * (VIT_D / 8);
         const int ch = q >> 5, ky = (q >> 1) & 15, kx0 = (q & 1) * 8;
@@ -532,7 +560,7 @@ hipError_t launch_resize_h(const uint8_t* pix, uint8_t* tmp, const CropDesc* cro
     return hipGetLastError();
 }
 
-hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n, const float* lut,
+hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, const CropDesc* crops, int n, const float* lut, const NormAffine& aff,
                                     void* patches, bool any_resize, const uint8_t* tab, int kv_max, hipStream_t s) {
     if (n <= 0) return hipSuccess;
     // the LDS window is only needed when some crop is resized or partially fills the canvas; the
@@ -545,9 +573,9 @@ hipError_t launch_resize_v_patchify(const uint8_t* pix, const uint8_t* tmp, cons
         const int window = (win_kb < 1 ? 1 : (win_kb > 96 ? 96 : win_kb)) * 1024;
         const int smem = kk_bytes + window + DMA_SLACK;
         if (hipError_t e = ensure_dynamic_lds((const void*)resize_v_patchify<true>, smem); e != hipSuccess) return e;
-        hipLaunchKernelGGL(resize_v_patchify<true>, dim3(n * VIT_GRID), dim3(512), smem, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, window, kvs);
+        hipLaunchKernelGGL(resize_v_patchify<true>, dim3(n * VIT_GRID), dim3(512), smem, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, window, kvs, aff);
     } else {
-        hipLaunchKernelGGL(resize_v_patchify<false>, dim3(n * VIT_GRID), dim3(256), kk_bytes, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, 0, kvs);
+        hipLaunchKernelGGL(resize_v_patchify<false>, dim3(n * VIT_GRID), dim3(256), kk_bytes, s, pix, tmp, crops, lut, (bf16_t*)patches, tab, 0, kvs, aff);
     }
     return hipGetLastError();
 }
