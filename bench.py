@@ -78,6 +78,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-ln-fusion", action="store_true", help="separate LayerNorm kernel instead of folding it into the GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-from-host", action="store_true", help="skip the secondary PCIe-inclusive measurement (value_from_host)")
+    ap.add_argument("--no-c4-share", action="store_true", help="skip the secondary 8192-crop C4-share measurement of the N = 1 line")
+    ap.add_argument("--headline-only", action="store_true", help="= --no-cpu-baseline --no-from-host --no-c4-share (profiler passes)")
     ap.add_argument("--timeout", type=float, default=570.0, help="seconds the self-started multi-rank run may take before every rank is stopped (0: unbounded)")
     return ap.parse_args(argv)
 
@@ -281,6 +283,8 @@ def c3_inputs(n, dev):
 
 def main():
     args = parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_from_host = args.no_c4_share = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.timeout))
 
@@ -522,7 +526,7 @@ def main():
             labels_equal = out["c5"].get("labels_equal_oracle")
         if parity is not None:
             out["parity_max_1_minus_cos_vs_oracle"] = parity
-        if world == 1 and config == "c2" and not args.crops:
+        if world == 1 and config == "c2" and not args.crops and not args.no_c4_share:
             out["c4_share_at_this_n"] = c4_share_line(eng, weights, dev, args)
         if world == 1 and config in ("c2", "c3") and not args.no_from_host:
             out["value_from_host"] = from_host_line(eng, config, crops_host, pix if config == "c3" else None,

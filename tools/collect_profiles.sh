@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 rm -rf "$OUT"  # gpurun merges into an existing gpurun_out/: stale pass files of an earlier call would be folded in twice
 mkdir -p "$OUT"
 cd /tmp
-BENCH="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $R/bench.py --steps 2 --warmup 1 --headline-only"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- $BENCH > "$OUT/kt.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$OUT/sq" -- $BENCH > "$OUT/sq.log" 2>&1
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/grbm" -- $BENCH > "$OUT/grbm.log" 2>&1

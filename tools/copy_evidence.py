@@ -21,7 +21,8 @@ def main():
         if os.path.exists(log):
             keep = [l for l in open(log, errors="replace") if not any(s in l for s in ("amdgpu.ids", "rocprofv3]", "output_stream.cpp", "simple_timer.cpp"))]
             open(os.path.join(dst, f"{tag}_{tool}.txt"), "w").writelines(keep)
-    for name in ("bench_c2.json", "bench_c4_1gpu.json", "bench_gloo_2ranks_1gpu.json", "gemm_stamps.log", "attn_stamps.log"):
+    for name in ("bench_c2.json", "bench_c3.json", "bench_c4_1gpu.json", "bench_c5.json", "bench_gloo_2ranks_1gpu.json", "bench_gloo_2ranks_1gpu_c5.json",
+                 "bench_from_host.log", "gemm_stamps.log", "attn_stamps.log", "attn_ab.log", "k1_ab.log"):
         f = os.path.join(src, name)
         if os.path.exists(f):
             lines = [l for l in open(f, errors="replace") if "amdgpu.ids" not in l]

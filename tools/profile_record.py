@@ -5,7 +5,7 @@ and uses for `roofline.traffic`) and copy the per-kernel summaries next to it.
     python tools/profile_record.py <dir> <tag> [--crops 4096] [--steps 3]      (steps = timed + warm-up passes in the trace)
 
 <dir> holds the passes, each written by `rocprofv3 ... -d <dir>/<pass> --output-format csv -- python3 bench.py --steps 2 --warmup 1
---no-cpu-baseline`:
+--headline-only`:
     kt      --kernel-trace --stats
     sq      --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES
     grbm    --kernel-trace --pmc GRBM_GUI_ACTIVE
@@ -92,7 +92,7 @@ def main():
         sha = ""
     gemm_ms_step = sum(v["avg_ms"] * v["dispatches"] for k, v in kernels.items() if k.startswith("gemm_bf16_tn")) / steps
     rec = {
-        "what": "separate rocprofv3 passes of `python3 bench.py --steps %d --warmup 1 --no-cpu-baseline` (kernel trace; SQ; GRBM; FETCH_SIZE; WRITE_SIZE), folded by tools/profile_record.py" % (steps - 1),
+        "what": "separate rocprofv3 passes of `python3 bench.py --steps %d --warmup 1 --headline-only` (kernel trace; SQ; GRBM; FETCH_SIZE; WRITE_SIZE), folded by tools/profile_record.py" % (steps - 1),
         "tag": tag, "git": sha, "source_hash": kernel_source_hash(),  # of csrc/ + mme.h: bench.py marks the record stale when it differs
         "crops_per_gpu": crops, "steps_traced": steps,
         "gemm_traffic_per_launch": gemm_bytes / gemm_n if gemm_n else None,
