@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Randomised parity sweeps of the GPU kernels against the oracle (run on a GPU box; ~1.5 minutes):
 
-    python tools/fuzz_parity.py [k1 neighbours fused pages cluster nms]
+    python tools/fuzz_parity.py [k1 neighbours fused pages cluster nms attention]
 
   k1          480 random crop sizes (tiny, extreme aspect, near 224, large): patches and Mllama tiles bit-exact
   neighbours   60 random (N, D, fetch, top_n, groups, duplicates, score windows): indices and values exact
   fused        14 problems of 16-42 k rows: fused K12 form == block form (overflow fallback included)
   pages        25 random page tables (empty pages, > 256 regions, zero areas, foreign types, both metrics): 1e-12
   cluster      40 random page matrices x 2 modes x (auto, fixed k): labels and k exact, heavy ties included
+  attention    24 weight sets (query / key weights scaled 1x..24x, so that scores spread from a few to hundreds of log2 units)
+               x 16 random crops: the guarded fast softmax form (default) and the exact form against the f32 oracle -- finite; the
+               fast form's error <= 1.5 x the exact form's + 1e-4 (beyond ~4x the bf16 rounding of Q and K alone moves an
+               arg-max: BOTH forms then sit 1e-2..1e-1 from the oracle and from each other); bit-identical whenever every layer
+               was redone; the forced re-run always bit-identical to the exact form
   nms          60 batches of 1-12 random pages (0-900 boxes each; whole-pixel and fractional boxes, tied scores, 1-6
                classes, thresholds 0-0.95): kept indices and their order exact
 """
@@ -212,12 +217,50 @@ def fuzz_nms(eng, emb):
     return bad
 
 
+def fuzz_attention(eng, emb):
+    from multimodal_embeddings_amd._lib import Engine
+    from multimodal_embeddings_amd.weights import make_vit_weights
+
+    rng = np.random.default_rng(91)
+    base = make_vit_weights(seed=1)
+    bad = 0
+    from oracle import vit as ovit
+
+    arrays = [rng.integers(0, 256, (int(rng.integers(16, 500)), int(rng.integers(16, 500)), 3), dtype=np.uint8) for _ in range(16)]
+    pix, offs, hw = emb.pack(arrays)
+    patches = np.stack([opre.preprocess_to_patches(a) for a in arrays])
+    for it, scale in enumerate([1, 1.5, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 1]):
+        w = {k: (v * np.float32(scale) if (".q_proj.weight" in k or ".k_proj.weight" in k) else v) for k, v in base.items()}
+        e = Engine(0)
+        e.load_vit(w)
+        e.set_attention_mode("exact")
+        ref, _ = e.embed(pix, offs, hw)
+        e.set_attention_mode("fast")
+        got, _ = e.embed(pix, offs, hw)
+        redone = e.attention_redone()
+        e.set_attention_mode("fast_forced_redo")
+        forced, _ = e.embed(pix, offs, hw)
+        torch.cuda.synchronize()
+        want = ovit.vit_embed(patches, w)
+        err_fast = float(np.max(1.0 - np.sum(got.cpu().numpy() * want, axis=1)))
+        err_exact = float(np.max(1.0 - np.sum(ref.cpu().numpy() * want, axis=1)))
+        ok = (bool(torch.isfinite(got).all()) and err_fast <= 1.5 * err_exact + 1e-4 and torch.equal(forced, ref)
+              and (not all(redone) or torch.equal(got, ref)))
+        if not ok:
+            bad += 1
+            print("ATTENTION MISMATCH scale", scale, "fast", err_fast, "exact", err_exact, "redone", redone, "forced==exact", torch.equal(forced, ref), flush=True)
+        else:
+            print(f"  q/k weights x{scale}: max(1-cos) vs the f32 oracle: fast {err_fast:.2e}, exact {err_exact:.2e}; layers redone {sum(redone)}/12", flush=True)
+        e.close()
+    return bad
+
+
 def main():
     emb = RegionEmbedder()
     eng = emb.engine
     total = 0
     only = set(sys.argv[1:])  # e.g. `python tools/fuzz_parity.py k1` runs one sweep
-    for name, fn in [("k1", fuzz_k1), ("neighbours", fuzz_neighbours), ("fused", fuzz_fused), ("pages", fuzz_pages), ("cluster", fuzz_cluster), ("nms", fuzz_nms)]:
+    for name, fn in [("k1", fuzz_k1), ("neighbours", fuzz_neighbours), ("fused", fuzz_fused), ("pages", fuzz_pages), ("cluster", fuzz_cluster), ("nms", fuzz_nms), ("attention", fuzz_attention)]:
         if only and name not in only:
             continue
         t0 = time.time()
