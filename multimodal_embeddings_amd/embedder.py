@@ -218,9 +218,7 @@ class RegionEmbedder:
         """Per-context staging of the host <-> device pipeline of `_embed_list`: two slots, each a pinned input buffer, its
         device twin and a pinned result buffer (grown on demand, kept), two copy streams (the H2D and D2H engines run
         side by side) and the events that order them against the compute stream."""
-        st = getattr(self, "_pipes", None)
-        if st is None:
-            st = self._pipes = {}
+        st = self.__dict__.setdefault("_pipes", {})  # atomic: contexts are driven from one thread each, concurrently
         if dev_idx not in st:
             t = self.torch
             dev = t.device(self.devices[dev_idx])
