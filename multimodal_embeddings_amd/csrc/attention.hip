@@ -10,7 +10,7 @@
 //     item i is computed, and the Q fragments of item i+1 are prefetched into registers -- across crop boundaries too:
 //     after the workgroup's first item no memory latency is exposed.  One barrier per item.
 //   * waves 0..6 own the 7 query blocks of 32 (197 -> 224); wave 7 has none.  The 50 LDS-DMA pieces of an item are
-//     requested by wave 7 (24), wave 3 -- its SIMD partner -- (8) and waves 4..6 (6 each): one issuer alone needs
+//     requested by wave 7 (18), wave 3 -- its SIMD partner -- (8) and waves 4..6 (8 each; ATTN_SHARE_*): one issuer alone needs
 //     ~8 000 cycles per item for them (an LDS-DMA piece stalls its issuer ~160 cycles), which was the kernel's
 //     critical path in round 2 (round 3: 14.2 -> 11.6 ms per step from spreading the requests alone).
 //   * S^T = K . Q^T with mfma_f32_32x32x16_bf16: the accumulator has the QUERY on the lane and
