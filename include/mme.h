@@ -123,6 +123,13 @@ int mme_set_ln_fusion(mme_ctx* ctx, int mode);
  * Outputs of modes 0 and 1 agree to rounding (different rounding points of the probabilities), not bit for bit.
  * The query projection carries dh^-0.5 log2(e) in every mode (folded into W_q / b_q by mme_load_vit). */
 int mme_set_attention_mode(mme_ctx* ctx, int mode);
+/* Last-layer pruning (default OFF; no reference counterpart -- the reference computes the whole last hidden state and
+ * `last_pooling` then reads ONE token row of it, embedder.py:17-34).  With it on, the rows nothing reads are not computed:
+ * in the last layer only the query block that holds the pooled token is attended, and its o_proj / LayerNorm / MLP run on
+ * the n gathered rows instead of n x 197 (6.2 % of the forward's FLOP).  Same kernels, same per-row arithmetic: the
+ * embeddings are bit-identical to the full pass.  Off by default so that the headline benchmark times the WHOLE forward
+ * (bench.py reports the pruned rate separately); applies to the LayerNorm-folded modes (mme_set_ln_fusion 1 / 2). */
+int mme_set_forward_pruning(mme_ctx* ctx, int on);
 /* Diagnostic (synchronises the device): flags[l] != 0 when the attention launch of layer l of the LAST encoder pass
  * raised its guard and was redone by the exact kernel. */
 int mme_attention_redone(mme_ctx* ctx, int32_t flags[12]);

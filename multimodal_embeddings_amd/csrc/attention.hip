@@ -72,7 +72,7 @@ __device__ __forceinline__ float other_half(float x) {
 template <int NB, bool STAMP, int PIPE>
 __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, const int nblk, const int hsplit,
                                           unsigned long long* stamps, const int dbg_arg, int* __restrict__ guard, const int share,
-                                          const float guard_limit) {
+                                          const float guard_limit, const int only_block) {
     // ablation switches of the STAMPED build only (results invalid): 1 no K re-reads, 2 no K/V requests after the
     // first head, 4 no maximum, 8 no exponentials
     const int dbg = STAMP ? dbg_arg : 0;
@@ -150,7 +150,9 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ qkv, bf16_t
     // uploaded, capi.hip), so a score leaves the matrix pipe in log2 units
     constexpr bool PRESCALED = true;
     const int q = wave * 32 + r;                      // this lane's query (waves 0..6)
-    const bool active = wave < 7;
+    // only_block >= 0: only that query block is computed and stored (the last layer when nothing but the pooled token's row
+    // is read afterwards, mme_set_forward_pruning); the other waves still take their share of the K/V requests
+    const bool active = wave < 7 && (only_block < 0 || wave == only_block);
     // this lane's Q row of an item: 4 x 16 bytes at + ks * 32
     auto q_ptr = [&](int it) {
         return (const char*)qkv + ((size_t)item_crop(it) * VIT_T + min(q, VIT_T - 1)) * QKV_LD + hh * 16 + item_head(it) * ROWB;
@@ -457,14 +459,16 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ qkv, bf16_t
 template <int NB, bool STAMP = false, int PIPE = 1>
 __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int nblk, int hsplit,
                                                          unsigned long long* stamps = nullptr, int dbg_arg = 0, int* __restrict__ guard = nullptr,
-                                                         int share = 0, const int* __restrict__ run_if = nullptr, float guard_limit = 1.2676506e30f) {
+                                                         int share = 0, const int* __restrict__ run_if = nullptr, float guard_limit = 1.2676506e30f,
+                                                         int only_block = -1) {
     if (run_if && *(const volatile int*)run_if == 0) return;  // uniform: every wave of every workgroup takes the same way
-    attn_body<NB, STAMP, PIPE>(qkv, out, nblk, hsplit, stamps, dbg_arg, guard, share, guard_limit);
+    attn_body<NB, STAMP, PIPE>(qkv, out, nblk, hsplit, stamps, dbg_arg, guard, share, guard_limit, only_block);
 }
 
 }  // namespace
 
-hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard, bool force_redo) {
+hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard, bool force_redo, int only_block) {
+    if (only_block < -1 || only_block > 6) return hipErrorInvalidValue;
     if (B <= 0) return hipSuccess;
     // blocks of 12 / hsplit heads: enough of them for every CU (one workgroup fits per CU: 112 KiB of LDS)
     int hsplit = 1;
@@ -484,14 +488,14 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, in
         // kernel left the range its reference point covers (*guard raised; guard is zeroed by the caller per pass)
         if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2, false, 2>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
         hipLaunchKernelGGL((attn_fwd_t197<2, false, 2>), dim3(grid), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, nblk, hsplit,
-                           (unsigned long long*)nullptr, 0, guard, share, (const int*)nullptr, force_redo ? 0.5f : 1.2676506e30f);
+                           (unsigned long long*)nullptr, 0, guard, share, (const int*)nullptr, force_redo ? 0.5f : 1.2676506e30f, only_block);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
         hipLaunchKernelGGL((attn_fwd_t197<2>), dim3(grid), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, nblk, hsplit,
-                           (unsigned long long*)nullptr, 0, (int*)nullptr, ATTN_SHARE_EXACT, (const int*)guard);
+                           (unsigned long long*)nullptr, 0, (int*)nullptr, ATTN_SHARE_EXACT, (const int*)guard, 1.2676506e30f, only_block);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((attn_fwd_t197<2>), dim3(grid), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, nblk, hsplit,
-                       (unsigned long long*)nullptr, 0, (int*)nullptr, share, (const int*)nullptr);
+                       (unsigned long long*)nullptr, 0, (int*)nullptr, share, (const int*)nullptr, 1.2676506e30f, only_block);
     return hipGetLastError();
 }
 

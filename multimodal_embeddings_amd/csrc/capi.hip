@@ -287,9 +287,52 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g.bias = L.qkv_b; g.out = c->qkv.p; g.ldo = 3 * VIT_D;
             HIP_TRY(c, launch_gemm(EPI_BIAS, g, s, c->gemm_variant));
         }
+        // Pruned last layer (mme_set_forward_pruning): after the last attention only ONE token row per crop is ever read
+        // (K8 pools token `pool_token`), so the query block that holds it is the only one attended, and o_proj, LayerNorm,
+        // fc1 and fc2 run on the n gathered rows instead of n x 197.  Same kernels, same per-row arithmetic: the
+        // embeddings are bit-identical to the full pass (tests/test_gpu_parity.py).
+        const bool pruned = c->prune_last && l + 1 == VIT_L && c->ln_mode != 0;
         {
             Timed t(c, s, KC_ATTN);
-            HIP_TRY(c, launch_attention(c->qkv.p, c->att.p, n, s, c->attn_mode ? (int*)c->attn_guard.p + l : nullptr, c->attn_mode == 2));
+            HIP_TRY(c, launch_attention(c->qkv.p, c->att.p, n, s, c->attn_mode ? (int*)c->attn_guard.p + l : nullptr, c->attn_mode == 2,
+                                        pruned ? pool_token / 32 : -1));
+        }
+        if (pruned) {
+            bf16_t* att_p = (bf16_t*)c->hbuf.p;          // [n, 768] gathered attention rows
+            bf16_t* x_p = att_p + (size_t)n * VIT_D;      // [n, 768] gathered residual rows (hbuf holds rows x 768: n x 197 of them)
+            const size_t rowb = (size_t)VIT_D * 2, pitch = (size_t)VIT_T * rowb;
+            {
+                Timed t(c, s, KC_POOL);
+                HIP_TRY(c, hipMemcpy2DAsync(att_p, rowb, (const char*)c->att.p + (size_t)pool_token * rowb, pitch, rowb, n, hipMemcpyDeviceToDevice, s));
+                HIP_TRY(c, hipMemcpy2DAsync(x_p, rowb, (const char*)c->x.p + (size_t)pool_token * rowb, pitch, rowb, n, hipMemcpyDeviceToDevice, s));
+            }
+            {
+                Timed t(c, s, KC_GEMM);
+                g = GemmArgs{};
+                g.A = att_p; g.W = L.o_w; g.M = n; g.N = VIT_D; g.K = VIT_D;
+                g.bias = L.o_b; g.out = x_p; g.res = x_p; g.ldo = VIT_D;
+                HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
+            }
+            {
+                Timed t(c, s, KC_LN);
+                HIP_TRY(c, launch_ln_stats_canonical(x_p, 0, n, VIT_D, c->ln_eps, (float*)c->stats.p, s));
+            }
+            {
+                Timed t(c, s, KC_GEMM);
+                g = GemmArgs{};
+                g.A = x_p; g.W = L.fc1_wf; g.M = n; g.N = VIT_F; g.K = VIT_D;
+                g.bias = L.fc1_bf; g.colsum = L.fc1_cs; g.ln_stats = (const float*)c->stats.p; g.out = c->mlp.p; g.ldo = VIT_F;
+                HIP_TRY(c, launch_gemm(EPI_LN_BIAS_GELU, g, s, c->gemm_variant));
+                g = GemmArgs{};
+                g.A = c->mlp.p; g.W = L.fc2_w; g.M = n; g.N = VIT_D; g.K = VIT_F;
+                g.bias = L.fc2_b; g.out = x_p; g.res = x_p; g.ldo = VIT_D;
+                HIP_TRY(c, launch_gemm(EPI_BIAS_RES, g, s, c->gemm_variant));
+            }
+            {   // back into the residual stream, where the pooling kernel reads the row
+                Timed t(c, s, KC_POOL);
+                HIP_TRY(c, hipMemcpy2DAsync((char*)c->x.p + (size_t)pool_token * rowb, pitch, x_p, rowb, rowb, n, hipMemcpyDeviceToDevice, s));
+            }
+            continue;
         }
         {
             Timed t(c, s, KC_GEMM);
@@ -610,6 +653,12 @@ int mme_attention_redone(mme_ctx* c, int32_t flags[12]) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(flags, c->attn_guard.p, VIT_L * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MME_OK;
+}
+
+int mme_set_forward_pruning(mme_ctx* c, int on) {
+    if (!c) return MME_E_ARG;
+    c->prune_last = on != 0;
     return MME_OK;
 }
 

@@ -78,7 +78,8 @@ hipError_t launch_normalise_rows(const float* x, int64_t rows, int d, void* y, h
 // fused multi-head attention, T=197, dh=64, 12 heads; qkv [B*197, 2304] -> out [B*197, 768]
 // guard: device int, zero before the launch; non-null selects the FAST kernel + the conditional exact re-run (attention.hip)
 // force_redo: the fast kernel raises the guard for every row (test of the re-run path)
-hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard = nullptr, bool force_redo = false);
+// only_block >= 0: compute and store that query block of 32 only (0..6)
+hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard = nullptr, bool force_redo = false, int only_block = -1);
 // diagnostic: stamped build, stamps uint64[B][8][8]
 hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s);
 

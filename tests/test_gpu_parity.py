@@ -227,6 +227,36 @@ def test_attention_fast_form_guard_and_exact_rerun(engine, golden_dir):
     e.close()
 
 
+def test_last_layer_pruning_is_bit_identical(engine):
+    """mme_set_forward_pruning: after the last layer's attention only the pooled token's row is ever read (K8), so only the
+    query block that holds it is attended and o_proj / LayerNorm / fc1 / fc2 of that layer run on the n gathered rows.  Same
+    kernels, same per-row arithmetic -> embeddings bit-identical to the full pass, for both pooling rules, both LayerNorm
+    statistics modes, both softmax forms, a ragged batch and a single crop."""
+    crops = synthetic_crops(300, seed=13)
+    pix, offs, hw = _pack(list(crops))
+    try:
+        for attn in ("fast", "exact"):
+            engine.set_attention_mode(attn)
+            for mode in (2, 1):
+                engine.set_ln_fusion(mode)
+                for tok in (0, 196, 77):
+                    engine.set_forward_pruning(False)
+                    full32, full16 = engine.embed(pix, offs, hw, tok)
+                    engine.set_forward_pruning(True)
+                    got32, got16 = engine.embed(pix, offs, hw, tok)
+                    torch.cuda.synchronize()
+                    assert torch.equal(full32, got32) and torch.equal(full16.view(torch.int16), got16.view(torch.int16)), (attn, mode, tok)
+        engine.set_forward_pruning(False)
+        one_full, _ = engine.embed(pix[: 150528 + 16], offs[:1], hw[:1])
+        engine.set_forward_pruning(True)
+        one, _ = engine.embed(pix[: 150528 + 16], offs[:1], hw[:1])
+        assert torch.equal(one, one_full)
+    finally:
+        engine.set_forward_pruning(False)
+        engine.set_attention_mode("fast")
+        engine.set_ln_fusion(2)
+
+
 def test_embed_matches_transformers_golden(engine, golden_dir):
     """vit_cases.npz was produced by transformers.ViTModel itself (make_golden.py)."""
     g = np.load(os.path.join(golden_dir, "vit_cases.npz"))
