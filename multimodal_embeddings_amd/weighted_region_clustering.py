@@ -94,6 +94,30 @@ class RegionCollection:
 
     add = upsert
 
+    def update(self, ids, embeddings=None, documents=None, metadatas=None):
+        """chroma's `Collection.update` (image_processor.py:219-224): change the given fields of rows that EXIST; an unknown
+        id is skipped with a warning (chroma logs and ignores it), a field passed as None keeps its value."""
+        for k, i in enumerate(ids):
+            if i not in self._pos:
+                logger.warning(f"update: id {i!r} not in the collection")
+                continue
+            r = self._pos[i]
+            if embeddings is not None:
+                self.embeddings[r] = embeddings[k]
+            if documents is not None:
+                self.documents[r] = documents[k]
+            if metadatas is not None:
+                self.metadatas[r] = metadatas[k]
+        if embeddings is not None:
+            self._device_rows = None
+
+    def modify(self, name=None, metadata=None):
+        """chroma's `Collection.modify` as db_operations.py:50-52 uses it: replace the collection-level metadata."""
+        if metadata is not None:
+            self.metadata = dict(metadata)
+        if name is not None:
+            self.name = name
+
     def count(self):
         return len(self.ids)
 

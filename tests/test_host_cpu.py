@@ -454,6 +454,24 @@ def test_convert_to_rgb_composites_over_white_like_the_mllama_processor():
     assert convert_to_rgb(rgb) is rgb
 
 
+def test_collection_update_and_modify():
+    """The rest of the collection contract of SURVEY.md 8b: `update` (image_processor.py:219-224) changes fields of existing
+    rows only, `modify` / `.metadata` carry the collection-level settings as db_operations.py:50-52 reads and writes them."""
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection
+
+    col = RegionCollection()
+    col.upsert(ids=["a", "b"], embeddings=[[1.0, 0.0], [0.0, 1.0]], metadatas=[{"k": 1}, {"k": 2}], documents=["da", "db"])
+    col.update(ids=["b", "zzz"], metadatas=[{"k": 3}, {"k": 9}])
+    got = col.get(ids=["a", "b"])
+    assert got["metadatas"] == [{"k": 1}, {"k": 3}] and got["documents"] == ["da", "db"] and got["embeddings"][1] == [0.0, 1.0]
+    assert col.count() == 2  # the unknown id was not added
+    col.update(ids=["a"], embeddings=[[0.5, 0.5]])
+    assert col.get(ids=["a"])["embeddings"] == [[0.5, 0.5]]
+    current = col.metadata or {}
+    col.modify(metadata={**current, "hnsw_M": "32", "hnsw_ef": "200"})  # the call db_operations.py:50-52 makes
+    assert col.metadata["hnsw_M"] == "32" and col.metadata["hnsw_space"] == "cosine"
+
+
 def test_collection_where_filters_and_query_shape_without_gpu():
     """chroma-shaped `where` handling of RegionCollection (the filter of every reference call site is {"key": {"$eq": v}})."""
     from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection, _where_mask
