@@ -75,6 +75,7 @@ EXPORTS = {
     "mme_set_attention_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_attention_redone": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mme_set_forward_pruning": (C.c_int, [C.c_void_p, C.c_int]),
+    "mme_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
     "mme_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "mme_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mme_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -288,6 +289,10 @@ class Engine:
         """1 / "fast" (default): guarded fast softmax; 0 / "exact": row maximum first (see mme.h)."""
         m = {"exact": 0, "fast": 1, "fast_forced_redo": 2}.get(mode, mode)
         self._check(self.lib.mme_set_attention_mode(self.h, int(m)), "mme_set_attention_mode")
+
+    def set_tile_order(self, mode: int):
+        """0 upwards, 1 zig-zag between consecutive kernels (default), 2 attention downwards only; bit-identical results."""
+        self._check(self.lib.mme_set_tile_order(self.h, int(mode)), "mme_set_tile_order")
 
     def set_forward_pruning(self, on: bool):
         """Skip what nothing reads in the LAST layer (only the pooled token's row is computed after its attention):

@@ -90,8 +90,11 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ qkv, bf16_t
     const int n_items = nloc * hpw;
     if (n_items == 0) return;
     // item -> (crop base, head)
-    auto item_head = [&](int it) { const int j = it / hpw, blk = blockIdx.x + j * gridDim.x; return (blk % hsplit) * hpw + (it - j * hpw); };
-    auto item_crop = [&](int it) { return (int)((blockIdx.x + (it / hpw) * gridDim.x) / hsplit); };
+    // rev (share bit 17): walk the blocks from the LAST crop down (zig-zag order of consecutive kernels, capi.hip forward_chunk)
+    const bool rev = (share >> 17) & 1;
+    auto item_blk = [&](int it) { const int blk = blockIdx.x + (it / hpw) * gridDim.x; return rev ? nblk - 1 - blk : blk; };
+    auto item_head = [&](int it) { return (item_blk(it) % hsplit) * hpw + (it - (it / hpw) * hpw); };
+    auto item_crop = [&](int it) { return item_blk(it) / hsplit; };
 
     // V rows 200.. are never written by DMA: zero them once in every buffer (P is 0 there, but
     // 0 * garbage could be NaN).  Rows 197..199 receive clamped copies of row 196 (finite).
@@ -112,7 +115,7 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ qkv, bf16_t
         // share = a + 16 b + 256 c: waves 0-2 (the first-dispatched half: they lose the issue arbitration to their SIMD
         // partners 4-6, which run at priority 1) request a pieces each, waves 4-6 b each, wave 3 (whose SIMD partner is
         // the staging wave) c, the staging wave the rest
-        const int sa = share & 15, sb = (share >> 4) & 15, sc3 = share >> 8;
+        const int sa = share & 15, sb = (share >> 4) & 15, sc3 = (share >> 8) & 63;
         int p_begin, p_end, p_step = 3;
         if (wave < 3) { p_begin = wave; p_end = 3 * sa; }
         else if (wave == 3) { p_begin = 3 * (sa + sb); p_end = p_begin + sc3; p_step = 1; }
@@ -467,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_t197(const bf16_t* __restrict
 
 }  // namespace
 
-hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard, bool force_redo, int only_block) {
+hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard, bool force_redo, int only_block, bool reverse) {
     if (only_block < -1 || only_block > 6) return hipErrorInvalidValue;
     if (B <= 0) return hipSuccess;
     // blocks of 12 / hsplit heads: enough of them for every CU (one workgroup fits per CU: 112 KiB of LDS)
@@ -480,8 +483,9 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, in
     const char* pipe_env = diag_env("MME_ATTN_PIPE");  // 1: the exact kernel only (A/B)
     const bool fast = guard != nullptr && !(pipe_env && atoi(pipe_env) == 1);
     const char* share_env = diag_env("MME_ATTN_SHARE");  // K/V pieces requested by the computing waves (dma_head)
-    const int share = share_env ? atoi(share_env) : (fast ? ATTN_SHARE_FAST : ATTN_SHARE_EXACT);
+    int share = share_env ? atoi(share_env) : (fast ? ATTN_SHARE_FAST : ATTN_SHARE_EXACT);
     if (share < 0 || 3 * ((share & 15) + ((share >> 4) & 15)) + (share >> 8) > 2 * NPIECE) return hipErrorInvalidValue;
+    if (reverse) share |= 1 << 17;
     if (hipError_t e = ensure_dynamic_lds((const void*)attn_fwd_t197<2>, AttnGeom<2>::LDS_BYTES); e != hipSuccess) return e;
     if (fast) {
         // FAST kernel, then the exact kernel on the same launch geometry, which returns at once unless a row of the fast
@@ -491,7 +495,7 @@ hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, in
                            (unsigned long long*)nullptr, 0, guard, share, (const int*)nullptr, force_redo ? 0.5f : 1.2676506e30f, only_block);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
         hipLaunchKernelGGL((attn_fwd_t197<2>), dim3(grid), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, nblk, hsplit,
-                           (unsigned long long*)nullptr, 0, (int*)nullptr, ATTN_SHARE_EXACT, (const int*)guard, 1.2676506e30f, only_block);
+                           (unsigned long long*)nullptr, 0, (int*)nullptr, ATTN_SHARE_EXACT | (reverse ? 1 << 17 : 0), (const int*)guard, 1.2676506e30f, only_block);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((attn_fwd_t197<2>), dim3(grid), dim3(512), AttnGeom<2>::LDS_BYTES, s, (const bf16_t*)qkv, (bf16_t*)out, nblk, hsplit,

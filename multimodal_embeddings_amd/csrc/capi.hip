@@ -211,6 +211,13 @@ int set_lut(mme_ctx* c, const float mean[3], const float stdv[3]) {
 int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, float* emb_f32, bf16_t* emb_bf16, hipStream_t s) {
     const int M = n * VIT_T;
     GemmArgs g{};
+    // Zig-zag: consecutive kernels of the pass walk the rows in OPPOSITE directions, so a consumer starts on the rows its
+    // producer wrote last -- what is still in the 256 MiB Infinity Cache of a 1.2-5 GB activation -- instead of on the rows
+    // written first and long evicted.  Tile order only: results are bit-identical (tests).  dir flips at every producer.
+    const char* zz_env = diag_env("MME_ZIGZAG");
+    const int zigzag = zz_env ? atoi(zz_env) : c->zigzag;  // 0 off, 1 every kernel alternates, 2 only the attention walks backwards
+    int dir = 0;
+    auto next_dir = [&]() { if (zigzag == 1) dir ^= 1; return dir; };
     {
         Timed t(c, s, KC_GEMM);
         g.A = patches;
@@ -275,6 +282,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->x.p; g.W = L.qkv_wf; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
             g.bias = L.qkv_bf; g.colsum = L.qkv_cs; g.ln_stats = (const float*)c->stats.p; g.out = c->qkv.p; g.ldo = 3 * VIT_D;
+            g.reverse_m = next_dir();
             HIP_TRY(c, launch_gemm(EPI_LN_BIAS, g, s, c->gemm_variant));
         } else {
             {
@@ -285,6 +293,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->hbuf.p; g.W = L.qkv_w; g.M = M; g.N = 3 * VIT_D; g.K = VIT_D;
             g.bias = L.qkv_b; g.out = c->qkv.p; g.ldo = 3 * VIT_D;
+            g.reverse_m = next_dir();
             HIP_TRY(c, launch_gemm(EPI_BIAS, g, s, c->gemm_variant));
         }
         // Pruned last layer (mme_set_forward_pruning): after the last attention only ONE token row per crop is ever read
@@ -295,7 +304,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
         {
             Timed t(c, s, KC_ATTN);
             HIP_TRY(c, launch_attention(c->qkv.p, c->att.p, n, s, c->attn_mode ? (int*)c->attn_guard.p + l : nullptr, c->attn_mode == 2,
-                                        pruned ? pool_token / 32 : -1));
+                                        pruned ? pool_token / 32 : -1, zigzag == 2 ? true : next_dir() != 0));
         }
         if (pruned) {
             bf16_t* att_p = (bf16_t*)c->hbuf.p;          // [n, 768] gathered attention rows
@@ -340,6 +349,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g.A = c->att.p; g.W = L.o_w; g.M = M; g.N = VIT_D; g.K = VIT_D;
             g.bias = L.o_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
             g.ln_part = (float*)c->lnpart.p; g.ln_part_rows = (int64_t)c->ws_chunk * VIT_T;
+            g.reverse_m = next_dir();
             HIP_TRY(c, launch_gemm(res_epi, g, s, c->gemm_variant));
         }
         if (c->ln_mode != 0) {
@@ -348,6 +358,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->x.p; g.W = L.fc1_wf; g.M = M; g.N = VIT_F; g.K = VIT_D;
             g.bias = L.fc1_bf; g.colsum = L.fc1_cs; g.ln_stats = (const float*)c->stats.p; g.out = c->mlp.p; g.ldo = VIT_F;
+            g.reverse_m = next_dir();
             HIP_TRY(c, launch_gemm(EPI_LN_BIAS_GELU, g, s, c->gemm_variant));
         } else {
             {
@@ -358,6 +369,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g = GemmArgs{};
             g.A = c->hbuf.p; g.W = L.fc1_w; g.M = M; g.N = VIT_F; g.K = VIT_D;
             g.bias = L.fc1_b; g.out = c->mlp.p; g.ldo = VIT_F;
+            g.reverse_m = next_dir();
             HIP_TRY(c, launch_gemm(EPI_BIAS_GELU, g, s, c->gemm_variant));
         }
         const bool last = l + 1 == VIT_L;  // the final LayerNorm touches the pooled row only (K8)
@@ -367,6 +379,7 @@ int forward_chunk(mme_ctx* c, const bf16_t* patches, int n, int pool_token, floa
             g.A = c->mlp.p; g.W = L.fc2_w; g.M = M; g.N = VIT_D; g.K = VIT_F;
             g.bias = L.fc2_b; g.out = c->x.p; g.res = c->x.p; g.ldo = VIT_D;
             g.ln_part = (float*)c->lnpart.p; g.ln_part_rows = (int64_t)c->ws_chunk * VIT_T;
+            g.reverse_m = next_dir();
             HIP_TRY(c, launch_gemm(last ? EPI_BIAS_RES : res_epi, g, s, c->gemm_variant));
         }
         if (c->ln_mode != 0 && !last && (r = stats_after(g))) return r;
@@ -653,6 +666,13 @@ int mme_attention_redone(mme_ctx* c, int32_t flags[12]) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize());
     HIP_TRY(c, hipMemcpy(flags, c->attn_guard.p, VIT_L * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return MME_OK;
+}
+
+int mme_set_tile_order(mme_ctx* c, int mode) {
+    if (!c) return MME_E_ARG;
+    if (mode < 0 || mode > 2) return fail(c, MME_E_ARG, "mme_set_tile_order: 0 (every kernel walks the rows upwards), 1 (zig-zag, the default) or 2 (only the attention walks downwards)");
+    c->zigzag = mode;
     return MME_OK;
 }
 

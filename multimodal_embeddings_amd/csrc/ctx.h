@@ -54,6 +54,7 @@ struct mme_ctx {
     int ws_chunk = 0;
     DevBuf attn_guard;      // int[64]: one guard word per layer of a pass (attention.hip, FAST form)
     bool prune_last = false;  // mme_set_forward_pruning
+    int zigzag = 1;           // forward_chunk: 1 = consecutive kernels walk the rows in opposite directions, 2 = attention only
     int attn_mode = 1;      // mme_set_attention_mode: 0 exact, 1 fast (guarded), 2 fast with the guard forced (tests)
     DevBuf x, hbuf, qkv, att, mlp, stats, lnpart, patches, tmp, htab, crops, hwork, page_ws, cluster_ws, neigh_ws, zero_bias;
     // host staging for crop tables

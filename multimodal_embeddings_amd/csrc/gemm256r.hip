@@ -89,7 +89,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_tn_256r(GemmArgs g, int tile
         const int gsz = rows_blk * gn;
         const int grp = idb / gsz, rem = idb - grp * gsz;
         const int gw = min(gn, tiles_n - grp * gn);
-        const int tm = blk * rbs + rem / gw, tn = grp * gn + (rem - (rem / gw) * gw);
+        const int tm_f = blk * rbs + rem / gw, tn = grp * gn + (rem - (rem / gw) * gw);
+        const int tm = g.reverse_m ? tiles_m - 1 - tm_f : tm_f;
         c.m0 = tm * TM;
         c.n0 = tn * TN;
         c.Ag = (const char*)g.A + (size_t)((dbg & 3) == 2 ? 0 : c.m0) * ldb;

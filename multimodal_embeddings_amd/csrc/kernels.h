@@ -46,6 +46,7 @@ struct GemmArgs {
     int cand_cap;
     int* overflow;
     const int* run_if;      // optional: the whole launch is a no-op unless *run_if != 0 (device-side fallback switch)
+    int reverse_m;          // 256 x 256 kernel: walk the row panels from the LAST one down (same results; see forward_chunk, zig-zag)
 };
 
 // raises hipFuncAttributeMaxDynamicSharedMemorySize of `kernel` on the CURRENT device to at least `bytes`
@@ -79,7 +80,9 @@ hipError_t launch_normalise_rows(const float* x, int64_t rows, int d, void* y, h
 // guard: device int, zero before the launch; non-null selects the FAST kernel + the conditional exact re-run (attention.hip)
 // force_redo: the fast kernel raises the guard for every row (test of the re-run path)
 // only_block >= 0: compute and store that query block of 32 only (0..6)
-hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard = nullptr, bool force_redo = false, int only_block = -1);
+// reverse: walk the crops from the last one down (same results; zig-zag order of consecutive kernels, forward_chunk)
+hipError_t launch_attention(const void* qkv, void* out, int B, hipStream_t s, int* guard = nullptr, bool force_redo = false, int only_block = -1,
+                            bool reverse = false);
 // diagnostic: stamped build, stamps uint64[B][8][8]
 hipError_t launch_attention_stamped(const void* qkv, void* out, int B, unsigned long long* stamps, hipStream_t s);
 

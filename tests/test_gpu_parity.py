@@ -227,6 +227,21 @@ def test_attention_fast_form_guard_and_exact_rerun(engine, golden_dir):
     e.close()
 
 
+def test_tile_order_modes_are_bit_identical(engine):
+    """mme_set_tile_order changes only the ORDER in which the GEMMs walk their row panels and the attention its crops."""
+    crops = synthetic_crops(300, seed=21)
+    pix, offs, hw = _pack(list(crops))
+    try:
+        outs = []
+        for mode in (1, 0, 2):
+            engine.set_tile_order(mode)
+            outs.append(engine.embed(pix, offs, hw)[0].clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        engine.set_tile_order(1)
+
+
 def test_last_layer_pruning_is_bit_identical(engine):
     """mme_set_forward_pruning: after the last layer's attention only the pooled token's row is ever read (K8), so only the
     query block that holds it is attended and o_proj / LayerNorm / fc1 / fc2 of that layer run on the n gathered rows.  Same

@@ -44,6 +44,7 @@ def main():
             eng.set_ln_fusion(a[2] if len(a) > 2 else 2)
             os.environ["MME_ATTN_PIPE"] = str(a[3] if len(a) > 3 else 2)
             os.environ["MME_GEMM_RB"] = str(a[4] if len(a) > 4 else 0)
+            os.environ["MME_ZIGZAG"] = str(a[6]) if len(a) > 6 else "0"
             if len(a) > 5:
                 os.environ["MME_ATTN_SHARE"] = str(a[5])
             else:
@@ -66,7 +67,7 @@ def main():
                 print(f"arm {a}: embeddings differ from arm {arms[0]} (max 1-cos {float((1.0 - (ref * e32).sum(dim=1)).max()):.3e})", flush=True)
     for a in arms:
         t = sorted(times[a])
-        print(f"gemm variant {a[0]} attn bufs {a[1]} ln mode {a[2] if len(a) > 2 else 2} attn pipe {a[3] if len(a) > 3 else 1} gemm rb {a[4] if len(a) > 4 else 0} attn share {a[5] if len(a) > 5 else 'default'}: ms/step min {t[0]:.2f} med {t[len(t) // 2]:.2f} | "
+        print(f"gemm variant {a[0]} attn bufs {a[1]} ln mode {a[2] if len(a) > 2 else 2} attn pipe {a[3] if len(a) > 3 else 1} gemm rb {a[4] if len(a) > 4 else 0} attn share {a[5] if len(a) > 5 else 'default'} zigzag {a[6] if len(a) > 6 else 0}: ms/step min {t[0]:.2f} med {t[len(t) // 2]:.2f} | "
               + " ".join(f"{k} {v:.2f}" for k, v in kern[a].items()), flush=True)
 
 
