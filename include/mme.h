@@ -29,7 +29,8 @@ extern "C" {
  * 2 (round 3): mme_profile_read_sync takes the capacity of the caller's arrays (the class count is no longer part of
  *    the ABI); mme_set_ln_fusion's argument is a MODE (0 / 1 / 2, it was on / off in version 1); mme_tile_vit_weights
  *    carries the save point of the intermediate states; the experiment switches MME_GEMM_DEBUG / MME_ATTN_DEBUG exist
- *    only in a -DMME_DIAG build.  A binder checks `mme_abi_version() == MME_ABI_VERSION` right after dlopen. */
+ *    only in a -DMME_DIAG build; new exports mme_is_diag_build, mme_set_attention_mode, mme_attention_redone,
+ *    mme_set_tile_order, mme_set_forward_pruning.  A binder checks `mme_abi_version() == MME_ABI_VERSION` right after dlopen. */
 #define MME_ABI_VERSION 2
 
 enum {
