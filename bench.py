@@ -45,6 +45,7 @@ import sys
 import threading
 import time
 
+T_IMPORT = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -80,6 +81,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-from-host", action="store_true", help="skip the secondary PCIe-inclusive measurement (value_from_host)")
     ap.add_argument("--no-c4-share", action="store_true", help="skip the secondary 8192-crop C4-share measurement of the N = 1 line")
     ap.add_argument("--headline-only", action="store_true", help="= --no-cpu-baseline --no-from-host --no-c4-share (profiler passes)")
+    ap.add_argument("--force-dist", action="store_true", help="create the torch.distributed process group (nccl = RCCL on a GPU box) at "
+                    "WORLD_SIZE = 1 too and run every collective of the N > 1 path through it: the one-GPU rehearsal of the multi-GPU code")
     ap.add_argument("--timeout", type=float, default=570.0, help="seconds the self-started multi-rank run may take before every rank is stopped (0: unbounded)")
     return ap.parse_args(argv)
 
@@ -296,7 +299,8 @@ def main():
     from multimodal_embeddings_amd._lib import Engine
     from multimodal_embeddings_amd.weights import make_vit_weights, synthetic_crops, synthetic_page_structure
 
-    rank, world, local = mdist.init_from_env()
+    rank, world, local = mdist.init_from_env(force=args.force_dist)
+    use_dist = mdist.collectives_active()  # world > 1, or the forced process group of one rank
     if world != args.gpus:
         if rank == 0:
             print(f"error: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or run "
@@ -370,7 +374,7 @@ def main():
             torch.cuda.synchronize()
             t_b = time.perf_counter()
             c5["stage_s"]["embed"] += t_b - t_a
-        if world > 1:
+        if use_dist:
             if i >= 0:
                 gather_ev[i][0].record()
                 th = time.perf_counter()
@@ -401,10 +405,18 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # seconds from the creation of this rank's process to the first step: interpreter + torch import, process group,
+    # synthetic weights (a numpy hash generator, single-threaded) and crops, uploads -- N of these run side by side at N ranks
+    try:
+        import psutil
+
+        startup_s = time.time() - psutil.Process().create_time()
+    except Exception:  # noqa: BLE001
+        startup_s = time.time() - T_IMPORT
     for _ in range(args.warmup):
         step()
     fence()
@@ -417,10 +429,13 @@ def main():
     prof = eng.profile_read()
     eng.profile(False)
     per_rank = mdist.all_gather_floats(elapsed_local, dev)
+    startup_by_rank = mdist.all_gather_floats(startup_s, dev)
+    box = box_probe(eng, dev)  # which class of box every rank ran on: outside the timed region
+    box_by_rank = {k: mdist.all_gather_floats(v if v is not None else float("nan"), dev) for k, v in box.items()}
     elapsed = max(per_rank)
     steps = max(args.steps, 1)
     gather_ms = None
-    if world > 1 and args.steps > 0:
+    if use_dist and args.steps > 0:
         # device-side span of the collective on the launch stream (it includes waiting for the slowest rank's shard)
         gather_ms = max(mdist.all_gather_floats(sum(a.elapsed_time(b) for a, b in gather_ev[: args.steps]) / steps, dev))
 
@@ -486,15 +501,23 @@ def main():
                 "name": config,
                 "crops_per_gpu": n,
                 "table_rows": table_rows,
-                "parallelism": f"dp{world} (crop shards, one all-gather of bf16 embeddings, backend {dist.get_backend()})" if world > 1 else "single GPU",
+                "parallelism": f"dp{world} (crop shards, one all-gather of bf16 embeddings, backend {dist.get_backend()}"
+                               f"{'; process group forced at world size 1' if world == 1 else ''})" if use_dist else "single GPU",
                 "note": "the default line is C2 (4096 crops per GPU) at N = 1 and C4's per-rank share (8192 crops per GPU, weak scaling) at N > 1; "
                         "`c4_share_at_this_n` in the N = 1 line is the same 8192-crop share measured in this run, the figure a 1 -> N curve "
                         "should be read against",
             },
             "ms_per_step_by_rank": [t * 1e3 / steps for t in per_rank],
+            "startup_s_by_rank": startup_by_rank,
+            "box": {**{k: v[0] for k, v in box_by_rank.items()}, "by_rank": box_by_rank,
+                    "what": "hbm_copy_gbs: device-to-device copy of 1 GiB (read + written bytes / HIP-event time, ~50 ms of copies): boxes of this "
+                            "pool stream at ~3.9 or ~5.5 TB/s in K1 and differ up to 30 % on the HBM-bound kernels; gemm_clock_ghz: s_memtime / "
+                            "s_memrealtime of one stamped launch of the QKV-shaped GEMM after 0.5 s of the product kernel (mme_gemm_stamps)"},
+            "result_digest": result_digest(e32, table[: n * world], c5),
             "allgather_ms": gather_ms,
-            "allgather_host_ms": gather_host_s[0] * 1e3 / steps if world > 1 else None,
-            "allgather_bytes": float(n) * world * 768 * 2 if world > 1 else None,
+            "allgather_host_ms": gather_host_s[0] * 1e3 / steps if use_dist else None,
+            "allgather_bytes": float(n) * world * 768 * 2 if use_dist else None,
+            "attention_layers_redone_last_pass": int(sum(eng.attention_redone())),  # fast softmax form's guard (mme.h): 0 = no exact re-run
             "forward_mfma_frac": forward_frac if c5 is None else None,
             "forward_mfma_frac_note": "forward FLOP x this rank's crops/s / 2.5 PFLOP/s nominal dense peak (no clock adjustment), measured in this run",
             "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
@@ -575,9 +598,61 @@ def main():
             "max_cosine_error_vs_cpu_ref": parity, "labels_equal_oracle": labels_equal,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def box_probe(eng, dev):
+    """Two numbers that tell boxes apart: the rate of a plain device copy (HBM class) and the clock the chip holds
+    under the dominant GEMM.  ~0.6 s in all, after the timed region."""
+    import numpy as np
+    import torch
+
+    out = {"hbm_copy_gbs": None, "gemm_clock_ghz": None}
+    try:
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        src.random_(0, 256)
+        for _ in range(3):
+            dst.copy_(src)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 100
+        a.record()
+        for _ in range(reps):
+            dst.copy_(src)
+        b.record()
+        b.synchronize()
+        out["hbm_copy_gbs"] = 2.0 * nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+        del src, dst
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: copy probe failed: {e}", file=sys.stderr)
+    try:
+        st = eng.gemm_stamps(806912, 2304, 768).astype(np.float64)
+        ok = st[:, 0, 10] > 0
+        out["gemm_clock_ghz"] = float(np.median(st[ok, 0, 13] / np.maximum(st[ok, 0, 14], 1.0) * 0.1))
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: clock probe failed: {e}", file=sys.stderr)
+    return out
+
+
+def result_digest(e32, table_head, c5):
+    """sha256 of what the step produced (rank 0's f32 embeddings, the gathered bf16 table head, and for C5 the page
+    matrix and labels): two runs of the same configuration -- with and without the process group, say -- are
+    bit-identical exactly when these agree."""
+    import hashlib
+
+    import torch
+
+    def sha(t):
+        return hashlib.sha256(t.contiguous().view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:32]
+
+    out = {"embeddings_f32": sha(e32), "table_bf16": sha(table_head)}
+    if c5 is not None and c5["S"] is not None:
+        out["page_matrix_f64"] = sha(c5["S"])
+        out["labels"] = [int(v) for v in c5["labels"]]
+    return out
 
 
 def c4_share_line(eng, weights, dev, args):

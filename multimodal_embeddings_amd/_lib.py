@@ -12,9 +12,13 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MME_LIB_PATH: measurement tools point this at libmme_diag.so (build.py --diag), the only build that reads the
-# experiment switches of DESIGN.md 4.5; the product default is the in-tree libmme.so
-LIB_PATH = os.environ.get("MME_LIB_PATH") or os.path.join(_HERE, "libmme.so")
+# The product library is the in-tree libmme.so.  Measurement tools load libmme_diag.so (build.py --diag: the only build
+# that reads the experiment switches of DESIGN.md 4.5) by naming it in MME_LIB_PATH AND opting in with
+# MME_ALLOW_LIB_OVERRIDE=1 (tools/_diag.py sets both): one stray variable in a user's environment must not be able to
+# swap the library -- load_library refuses the override without the opt-in, and says so on stderr when a diagnostic
+# build is what got loaded.
+DEFAULT_LIB_PATH = os.path.join(_HERE, "libmme.so")
+LIB_PATH = os.environ.get("MME_LIB_PATH") or DEFAULT_LIB_PATH
 DIAG_LIB_PATH = os.path.join(_HERE, "libmme_diag.so")
 
 NUM_KERNEL_CLASSES = 10
@@ -117,6 +121,9 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    if path is None and os.path.abspath(p) != os.path.abspath(DEFAULT_LIB_PATH) and os.environ.get("MME_ALLOW_LIB_OVERRIDE") != "1":
+        raise MmeError(f"MME_LIB_PATH={p} names another library than the in-tree libmme.so; that is a measurement-tool switch "
+                       "(tools/_diag.py) and needs MME_ALLOW_LIB_OVERRIDE=1 beside it.  Unset MME_LIB_PATH to run the product library.")
     # torch ships its own libamdhip64; libmme.so must bind to THAT runtime (one HIP runtime per
     # process), so torch is always loaded first.  Loading libmme.so first makes the second
     # runtime report "no ROCm-capable device".
@@ -135,6 +142,11 @@ def load_library(path: str | None = None):
     if lib.mme_abi_version() != ABI_VERSION:
         raise MmeError(f"libmme ABI version {lib.mme_abi_version()} != {ABI_VERSION} (include/mme.h MME_ABI_VERSION): rebuild the library "
                        "(python -m multimodal_embeddings_amd.build --force) or update the binding")
+    if lib.mme_is_diag_build():
+        import sys
+
+        print(f"libmme: DIAGNOSTIC build loaded ({p}): it reads the MME_* experiment switches from the environment, some of which "
+              "produce wrong results on purpose; never use it for production embeddings", file=sys.stderr, flush=True)
     if path is None:
         _lib = lib
     return lib
@@ -316,10 +328,12 @@ class Engine:
             raise ValueError("offs and hw disagree")
         return offs, hw
 
-    def crop_boxes(self, page, boxes):
+    def crop_boxes(self, page, boxes, out=None, base: int = 0):
         """page: uint8 CUDA tensor [H, W, 3]; boxes: int array [n, 4] (x0, y0, x1, y1), already int()-truncated.
 
-        Returns (pix uint8 CUDA tensor, offs int64[n], hw int32[n, 2]) ready for `preprocess` / `embed`."""
+        Returns (pix uint8 CUDA tensor, offs int64[n], hw int32[n, 2]) ready for `preprocess` / `embed`.  With `out` (a
+        uint8 CUDA buffer) the crops are packed into it from byte `base` (a multiple of 16) on and `offs` are offsets
+        into `out`: the boxes of several pages fill ONE packed buffer (RegionProcessor.process_regions)."""
         t = self.torch
         if page.dtype != t.uint8 or page.dim() != 3 or page.shape[2] != 3 or not page.is_contiguous():
             raise MmeError("crop_boxes: page must be a contiguous uint8 [H, W, 3] tensor")
@@ -333,7 +347,12 @@ class Engine:
         if n > 1:
             offs[1:] = np.cumsum((size[:-1] + 15) // 16 * 16)
         total = int(offs[-1] + size[-1]) if n else 0
-        pix = t.empty(total + 16, dtype=t.uint8, device=page.device)
+        if out is not None:
+            if out.dtype != t.uint8 or not out.is_contiguous() or out.device != page.device or base % 16 or base < 0 or base + total + 16 > out.numel():
+                raise MmeError("crop_boxes: `out` must be a contiguous uint8 buffer on the page's device with room for the crops (+16 B) from a 16-byte aligned `base`")
+            pix, offs = out, offs + int(base)
+        else:
+            pix = t.empty(total + 16, dtype=t.uint8, device=page.device)
         self._check(self.lib.mme_crop_boxes(self.h, page.data_ptr(), int(page.shape[0]), int(page.shape[1]), b.ctypes.data, n,
                                             pix.data_ptr(), offs.ctypes.data, self._stream()), "mme_crop_boxes")
         return pix, offs, hw

@@ -255,10 +255,12 @@ __device__ __forceinline__ void attn_body(const bf16_t* __restrict__ qkv, bf16_t
                 }
                 float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]), mx1 = fmaxf(fmaxf(s[0][3], s[0][4]), s[0][5]);
 #pragma unroll
-                for (int e = 6; e < 16; e += 4) {
+                for (int e = 6; e < 14; e += 4) {  // elements 6..13; 14 and 15 below (every index < 16: ADVICE r3)
                     mx = fmaxf(fmaxf(mx, s[0][e]), s[0][e + 1]);
-                    mx1 = fmaxf(fmaxf(mx1, s[0][e + 2]), s[0][(e + 3) & 15]);
+                    mx1 = fmaxf(fmaxf(mx1, s[0][e + 2]), s[0][e + 3]);
                 }
+                mx = fmaxf(mx, s[0][14]);
+                mx1 = fmaxf(mx1, s[0][15]);
                 mx = fmaxf(mx, mx1);
                 mx = fmaxf(mx, other_half(mx));
                 f32x16 negm;

@@ -39,19 +39,39 @@ def shard_pages(page_offs, rank: int, world: int) -> tuple[int, int]:
     return int(cuts[rank]), int(cuts[rank + 1])
 
 
-def init_from_env(backend: str | None = None):
-    """torch.distributed init from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
+_FORCED = False  # init_from_env(force=True): the collectives run on a process group of ONE rank too
+
+
+def collectives_active() -> bool:
+    """True when the collectives of this module go through torch.distributed: a process group of more than one rank,
+    or one created with `force` (the world-size-1 rehearsal of the RCCL path: same calls, same buffers)."""
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
+
+
+def init_from_env(backend: str | None = None, force: bool = False):
+    """torch.distributed init from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+
+    `force` (or MME_FORCE_DIST=1) creates the process group at WORLD_SIZE = 1 as well and makes every collective of
+    this module go through it: on the one-GPU box that is the only way the nccl (= RCCL) branch -- communicator
+    creation on the device, `all_gather_into_tensor` straight into the table slice, the P x P all-reduce, barrier,
+    destroy -- runs before the first real multi-GPU launch does."""
+    global _FORCED
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    force = force or os.environ.get("MME_FORCE_DIST", "") not in ("", "0")
     if torch.cuda.is_available() and local >= torch.cuda.device_count():
         # more ranks than GPUs (a rehearsal on a smaller box): share devices round-robin; RCCL cannot
         # do that, so such a run needs MME_DIST_BACKEND=gloo
         local %= torch.cuda.device_count()
-    if world > 1 and not dist.is_initialized():
+    if force:
+        _FORCED = True
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -74,7 +94,7 @@ def all_gather_rows(local, counts=None, out=None):
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         if out is not None:
             out.copy_(local)
             return out
@@ -115,7 +135,7 @@ def all_gather_floats(value: float, device=None) -> list:
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return [float(value)]
     mine = torch.tensor([value], dtype=torch.float64, device=device)
     got = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
@@ -127,7 +147,7 @@ def all_reduce_max_float(value: float, device=None) -> float:
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not collectives_active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -138,7 +158,7 @@ def all_reduce_sum(t):
     """In-place sum over ranks (no-op without an initialised process group); returns t."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if collectives_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -188,7 +208,7 @@ def neighbours_sharded(engine, emb_all, group=None, *, rank=None, world=None, ga
     n = emb_all.shape[0]
     lo, hi = shard_range(n, rank, world)
     idx, sim = engine.neighbours(emb_all, group, row0=lo, nrows=hi - lo, **kwargs)
-    if not gather or world == 1:
+    if not gather or not collectives_active():
         return idx, sim
     counts = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
     return all_gather_rows(idx, counts), all_gather_rows(sim, counts)

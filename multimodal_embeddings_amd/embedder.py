@@ -235,6 +235,7 @@ class RegionEmbedder:
                 st[dev_idx] = {
                     "in_stream": mk_stream(), "out_stream": mk_stream(), "compute": None if dev.type == "cuda" else _Null(),
                     "pin": [None, None], "dev": [None, None], "out": [None, None], "pinned": dev.type == "cuda",
+                    "used": [False, False],  # a slot's events mean something once it has been staged, in ANY earlier call
                     "ev_in": [mk_event(), mk_event()], "ev_done": [mk_event(), mk_event()], "ev_out": [mk_event(), mk_event()],
                 }
         return st[dev_idx]
@@ -248,7 +249,7 @@ class RegionEmbedder:
             return contextlib.nullcontext()
         return t.cuda.stream(stream) if stream is not None else t.cuda.device(dev)
 
-    def _stage_group(self, pipe, slot, arrays, device, first_use):
+    def _stage_group(self, pipe, slot, arrays, device):
         """Pack decoded crops into the slot's pinned buffer (16-byte aligned, as `pack`) and start their H2D copy on the
         input stream.  Returns (device pixels, offs, hw).  The slot's previous occupants are out of the way: the caller
         acquired the slot after the consumer recorded `ev_done[slot]` (the pass that read the device twin)."""
@@ -260,7 +261,12 @@ class RegionEmbedder:
         if n > 1:
             offs[1:] = np.cumsum((sizes[:-1] + 15) // 16 * 16)
         total = int(offs[-1] + sizes[-1]) + 16
+        first_use = not pipe["used"][slot]  # per pipe state, not per call: a call that left through an exception may have
+        pipe["used"][slot] = True           # work in flight on the buffers the next call finds
         if pipe["pin"][slot] is None or pipe["pin"][slot].numel() < total:
+            if not first_use:  # the buffers about to be dropped may still be read: by the last H2D, by the last pass
+                pipe["ev_in"][slot].synchronize()
+                pipe["ev_done"][slot].synchronize()
             cap = max(total, 1 << 20)
             pipe["pin"][slot] = t.empty(cap, dtype=t.uint8, pin_memory=pipe["pinned"])
             pipe["dev"][slot] = t.empty(cap, dtype=t.uint8, device=device)
@@ -313,7 +319,6 @@ class RegionEmbedder:
         step = max(1, int(self._group_crops))
         ready = queue.Queue(maxsize=2)
         slot_free = [threading.Semaphore(1), threading.Semaphore(1)]
-        used = [False, False]
         stop = threading.Event()
 
         def load(pair):
@@ -356,8 +361,7 @@ class RegionEmbedder:
                                 if stop.is_set():
                                     return
                             try:
-                                staged = self._stage_group(pipe, slot, [a for _, a in group], device, not used[slot])
-                                used[slot] = True
+                                staged = self._stage_group(pipe, slot, [a for _, a in group], device)
                                 ready.put(("group", slot, [i for i, _ in group], staged))
                             except Exception as e:  # embedder.py:223-224
                                 logger.error(f"Error in batch processing: {e}")
@@ -424,6 +428,10 @@ class RegionEmbedder:
                     pending = (slot, idx, n, e32)
                 if pending is not None:
                     finalize(pending)
+        except BaseException:
+            if device.type == "cuda":  # leave nothing in flight on the staging buffers the next call will reuse
+                t.cuda.synchronize(device)
+            raise
         finally:
             stop.set()
             while producer.is_alive():  # drain so that a blocked put() returns

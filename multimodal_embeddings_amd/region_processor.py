@@ -71,51 +71,74 @@ def region_rows(image_path, regions, region_types=None):
     return ids, metas, np.asarray(boxes, dtype=np.int32).reshape(-1, 4)
 
 
-class RegionProcessor:
-    """Same constructor shape and entry point as region_processor.py:RegionProcessor.
+class CachedRegionDetector:
+    """The cache half of `DocLayoutDetector.detect_regions` (doclayout_detector.py:99-120): the regions of a page come from
+    `<cache_folder>/<page-stem>_conf<c>_iou<i>.json` when that file exists.  Detection itself (DocLayout-YOLO) is out of
+    scope: a page without a cache file has no regions here (None, as the reference returns on failure)."""
 
-    `embedder` is a `RegionEmbedder`; `collection` anything with chroma's `upsert`.  `detector` is
-    not needed: crops are cut on the GPU from the decoded page."""
+    def __init__(self, cache_folder, conf_threshold=0.1, iou_threshold=0.45):
+        self.cache_folder, self.conf_threshold, self.iou_threshold = cache_folder, conf_threshold, iou_threshold
+
+    def cache_path(self, image_path):
+        stem = os.path.splitext(os.path.basename(image_path))[0]
+        return os.path.join(self.cache_folder, f"{stem}_conf{self.conf_threshold}_iou{self.iou_threshold}.json")
+
+    def detect_regions(self, image_path, force_recompute=False):
+        path = self.cache_path(image_path)
+        if not os.path.exists(path):
+            logger.error(f"Error detecting regions in {os.path.basename(image_path)}: no cached regions at {path}")
+            return None
+        try:
+            regions = load_region_cache(path)
+            logger.info(f"Loaded cached regions for {os.path.basename(image_path)}")
+            return regions
+        except Exception as e:  # noqa: BLE001
+            logger.warning(f"Error loading cached regions: {e}.")
+            return None
+
+
+class RegionProcessor:
+    """Same constructor shape and entry points as region_processor.py:RegionProcessor.
+
+    `embedder` is a `RegionEmbedder`; `collection` anything with chroma's `upsert`.  `detector` is only asked for
+    `detect_regions(image_path, force_recompute)` by `process_regions` (a `CachedRegionDetector`, or the reference's
+    own detector object): crops are never cut by it, they are cut on the GPU from the decoded page."""
+
+    WAVE_CROPS = 1024       # crops a device pass of `process_regions` should carry at least (the encoder's rate per crop
+    WAVE_BYTES = 1 << 30    # flattens out from ~1k crops per pass, DESIGN 6) ... and at most this many packed pixel bytes
+    DECODE_AHEAD = 4        # pages decoded ahead of the device, on threads (Pillow releases the GIL while decoding)
 
     def __init__(self, embedder, collection, detector=None):
         self.embedder, self.collection, self.detector = embedder, collection, detector
+
+    def _page_to_device(self, page):
+        from .embedder import _load_rgb
+
+        t = self.embedder.torch
+        arr = page if isinstance(page, np.ndarray) and page.dtype == np.uint8 and page.ndim == 3 else _load_rgb(page)
+        dev = t.device(f"cuda:{self.embedder.engine.device}")
+        return t.from_numpy(np.require(arr, requirements=["C", "W"])).to(dev)
 
     def embed_page_regions(self, page, int_boxes):
         """page: path | PIL image | uint8[H,W,3]; int_boxes int32[n,4] -> float32 CUDA tensor [n, 768].
 
         Boxes of zero or negative size (which make the reference's PNG save fail, :115-117) raise."""
-        from .embedder import _load_rgb
-
-        t = self.embedder.torch
-        arr = _load_rgb(page)
-        dev = t.device(f"cuda:{self.embedder.engine.device}")
-        page_dev = t.from_numpy(np.require(arr, requirements=["C", "W"])).to(dev)
-        pix, offs, hw = self.embedder.engine.crop_boxes(page_dev, int_boxes)
+        pix, offs, hw = self.embedder.engine.crop_boxes(self._page_to_device(page), int_boxes)
         e32, _ = self.embedder.embed_packed(pix, offs, hw, want_bf16=False)
         return e32
 
-    def process_image_regions(self, image_path, regions, page=None):
-        """region_processor.py:62-158: embed the page's regions and upsert them; returns the count.
-
-        `page` overrides the pixels read from `image_path` (already decoded page)."""
-        image_filename = os.path.basename(image_path)
-        if not regions.get("boxes"):
-            return 0
+    def _page_rows(self, image_path, regions):
+        """Rows of one page that will be embedded: (ids, metas, boxes, good) with the reference's warnings (:85-87)."""
         ids, metas, boxes = region_rows(image_path, regions)
-        if not ids:
-            return 0
         good = [k for k in range(len(ids)) if boxes[k, 2] > boxes[k, 0] and boxes[k, 3] > boxes[k, 1]]
         for k in sorted(set(range(len(ids))) - set(good)):
-            logger.warning(f"Failed to extract region {metas[k]['region_index']} from {image_filename}")  # :85-87
-        if not good:
-            return 0
-        try:
-            emb = self.embed_page_regions(image_path if page is None else page, boxes[good]).cpu().tolist()
-        except (MmeError, OSError, ValueError) as e:
-            logger.error(f"Error in batch processing: {e}")  # embedder.py:223-224: every region of the page fails
-            return 0
+            logger.warning(f"Failed to extract region {metas[k]['region_index']} from {os.path.basename(image_path)}")
+        return ids, metas, boxes, good
+
+    def _upsert_page(self, image_filename, ids, metas, good, emb):
+        """:124-154: the page's rows go to the store in chunks of REGION_BATCH_SIZE, in detector order."""
         embedded_count = 0
-        for i in range(0, len(good), config.REGION_BATCH_SIZE):  # same upsert granularity as :124-152
+        for i in range(0, len(good), config.REGION_BATCH_SIZE):
             sel = good[i : i + config.REGION_BATCH_SIZE]
             batch_meta = [metas[k] for k in sel]
             documents = [f"Region: {m['region_type']} from {m['parent_image_name']}" for m in batch_meta]
@@ -127,3 +150,274 @@ class RegionProcessor:
             except Exception as e:  # :153-154
                 logger.error(f"DB Error: {e}")
         return embedded_count
+
+    def process_image_regions(self, image_path, regions, page=None):
+        """region_processor.py:62-158: embed the page's regions and upsert them; returns the count.
+
+        `page` overrides the pixels read from `image_path` (already decoded page).  One device pass per page: a caller
+        with many pages should use `process_regions`, which fills the passes across pages."""
+        image_filename = os.path.basename(image_path)
+        if not regions.get("boxes"):
+            return 0
+        ids, metas, boxes, good = self._page_rows(image_path, regions)
+        if not good:
+            return 0
+        try:
+            emb = self.embed_page_regions(image_path if page is None else page, boxes[good]).cpu().tolist()
+        except (MmeError, OSError, ValueError) as e:
+            logger.error(f"Error in batch processing: {e}")  # embedder.py:223-224: every region of the page fails
+            return 0
+        return self._upsert_page(image_filename, ids, metas, good, emb)
+
+    def _wave_pipe(self):
+        """Staging of `process_regions`, created once per processor: a copy stream (page uploads + K0), a result stream, two
+        pinned page buffers, one device page buffer, two packed-crop wave buffers and the events that order them."""
+        if getattr(self, "_pipe", None) is None:
+            from .embedder import _Null
+
+            t = self.embedder.torch
+            dev = t.device(self.embedder.device)
+            cuda = dev.type == "cuda"
+            mk_stream, mk_event = ((lambda: t.cuda.Stream(dev)), t.cuda.Event) if cuda else (_Null, _Null)
+            self._pipe = {"dev": dev, "cuda": cuda, "in_stream": mk_stream(), "out_stream": mk_stream(),
+                          "pin": [None, None], "ev_pin": [mk_event(), mk_event()], "pin_used": [False, False], "page_dev": None,
+                          "pix": [None, None], "ev_ready": [mk_event(), mk_event()], "ev_done": [mk_event(), mk_event()],
+                          "ev_out": [mk_event(), mk_event()], "out": [None, None], "slot_used": [False, False]}
+        return self._pipe
+
+    def process_regions(self, image_paths, force_recompute=False, *, regions_by_path=None, pages=None, as_lists=True):
+        """region_processor.py:36-60 `process_regions(image_paths, force_recompute)`: every page's regions embedded and
+        upserted, page by page in `image_paths` order; returns the number of regions processed.
+
+        The reference calls `process_image_regions` per page, i.e. the embedder sees 5 ... 220 crops at a time (<= 48 per
+        call, :124-129) -- a device pass of this engine reaches its rate from ~1k crops on.  Here the boxes of SEVERAL
+        pages fill one pass ("wave"), and the host side runs under the device passes:
+          * pages are decoded ahead on threads (Pillow releases the GIL);
+          * a producer thread copies each page into one of two pinned buffers, uploads it on a copy stream and cuts its
+            boxes on the device (K0) straight into the wave's packed-crop buffer; a wave closes at >= WAVE_CROPS crops
+            (or WAVE_BYTES of pixels);
+          * this thread runs ONE `mme_embed` per wave, copies the rows back on a third stream and hands the rows of the
+            previous wave to the store -- per page, in page order, in the reference's chunks of REGION_BATCH_SIZE --
+            while the device works on the current one.
+        The contract per page is unchanged: an unreadable page is logged and skipped (`validate_image`, :43-45), a page
+        without regions is skipped with the reference's warning (:50-52), a page whose boxes cannot be cut or a failed
+        device pass voids exactly the pages concerned ("Error in batch processing"), a failed upsert voids its chunk.
+
+        `regions_by_path` (path -> regions dict) replaces `detector.detect_regions`; `pages` (path -> decoded uint8
+        [H, W, 3] array) replaces reading the file; `as_lists=False` upserts float32 ndarray rows instead of float lists."""
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+
+        from .embedder import _load_rgb
+
+        t = self.embedder.torch
+        engine = self.embedder.engine
+        pipe = self._wave_pipe()
+        dev, cuda = pipe["dev"], pipe["cuda"]
+        total_images = len(image_paths)
+        logger.info(f"Processing regions for {total_images} images")
+        on = (lambda stream: t.cuda.stream(stream)) if cuda else (lambda stream: __import__("contextlib").nullcontext())
+
+        def decode(path):
+            try:
+                if pages is not None and path in pages:
+                    return pages[path]
+                return _load_rgb(path)
+            except Exception as e:  # image_utils.py:26-35 validate_image
+                logger.error(f"Invalid image file {path}: {e}")
+                return None
+
+        def upload(arr, k):
+            """Page pixels -> the device page buffer, through pinned slot k & 1 (the copy into the pinned buffer of page
+            k + 1 runs while the DMA of page k is in flight)."""
+            arr = np.require(arr, requirements=["C"])
+            nb = arr.nbytes
+            s = k & 1
+            if pipe["pin"][s] is None or pipe["pin"][s].numel() < nb:
+                if pipe["pin_used"][s]:
+                    pipe["ev_pin"][s].synchronize()
+                pipe["pin"][s] = t.empty(max(nb, 1 << 24), dtype=t.uint8, pin_memory=cuda)
+            elif pipe["pin_used"][s]:
+                pipe["ev_pin"][s].synchronize()  # the DMA that last read this pinned buffer has finished
+            pipe["pin_used"][s] = True
+            hv = pipe["pin"][s].numpy()
+            flat = arr.reshape(-1)
+            workers = min(4, os.cpu_count() or 1, max(1, nb >> 25))  # large numpy copies release the GIL
+            if workers > 1:
+                cuts = [nb * w // workers for w in range(workers + 1)]
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    list(pool.map(lambda ab: hv.__setitem__(slice(ab[0], ab[1]), flat[ab[0]: ab[1]]), zip(cuts[:-1], cuts[1:])))
+            else:
+                hv[:nb] = flat
+            with on(pipe["in_stream"]):
+                if pipe["page_dev"] is None or pipe["page_dev"].numel() < nb:
+                    pipe["page_dev"] = t.empty(max(nb, 1 << 24), dtype=t.uint8, device=dev)  # same stream as its readers: ordered
+                pipe["page_dev"][:nb].copy_(pipe["pin"][s][:nb], non_blocking=True)
+                pipe["ev_pin"][s].record(pipe["in_stream"])
+            return pipe["page_dev"][:nb].view(arr.shape)
+
+        ready = queue.Queue(maxsize=2)
+        slot_free = [threading.Semaphore(1), threading.Semaphore(1)]
+        stop = threading.Event()
+
+        def produce():
+            wave_no, n_up = 0, 0
+            cur = None  # open wave: {"slot", "pages": [(path, ids, metas, good)], "offs": [...], "hw": [...], "base", "crops"}
+
+            def open_wave(min_bytes):
+                nonlocal cur
+                slot = wave_no & 1
+                while not slot_free[slot].acquire(timeout=0.1):
+                    if stop.is_set():
+                        return False
+                need = max(self.WAVE_BYTES, min_bytes) + 16
+                if pipe["pix"][slot] is None or pipe["pix"][slot].numel() < need:
+                    if pipe["slot_used"][slot]:
+                        pipe["ev_done"][slot].synchronize()  # the pass that read the old buffer has run
+                    with on(pipe["in_stream"]):
+                        pipe["pix"][slot] = t.empty(need, dtype=t.uint8, device=dev)
+                if pipe["slot_used"][slot]:
+                    with on(pipe["in_stream"]):
+                        pipe["in_stream"].wait_event(pipe["ev_done"][slot])
+                pipe["slot_used"][slot] = True
+                cur = {"slot": slot, "pages": [], "offs": [], "hw": [], "base": 0, "crops": 0}
+                return True
+
+            def close_wave():
+                nonlocal cur, wave_no
+                if cur is None:
+                    return
+                if cur["pages"]:
+                    with on(pipe["in_stream"]):
+                        pipe["ev_ready"][cur["slot"]].record(pipe["in_stream"])
+                    ready.put(("wave", cur))
+                    wave_no += 1
+                else:
+                    slot_free[cur["slot"]].release()
+                cur = None
+
+            try:
+                with ThreadPoolExecutor(max_workers=self.DECODE_AHEAD) as pool:
+                    futures = {k: pool.submit(decode, image_paths[k]) for k in range(min(self.DECODE_AHEAD, total_images))}
+                    for idx, image_path in enumerate(image_paths):
+                        if stop.is_set():
+                            return
+                        arr = futures.pop(idx).result()
+                        if idx + self.DECODE_AHEAD < total_images:
+                            futures[idx + self.DECODE_AHEAD] = pool.submit(decode, image_paths[idx + self.DECODE_AHEAD])
+                        if (idx + 1) % 5 == 0 or idx == total_images - 1:
+                            logger.info(f"Region processing progress: {idx + 1}/{total_images} images")
+                        if arr is None:
+                            logger.error(f"Skipping invalid image: {image_path}")  # :43-45
+                            continue
+                        image_filename = os.path.basename(image_path)
+                        try:
+                            regions = regions_by_path.get(image_path) if regions_by_path is not None else self.detector.detect_regions(image_path, force_recompute)
+                        except Exception as e:  # noqa: BLE001
+                            logger.error(f"Error detecting regions in {image_filename}: {e}")
+                            regions = None
+                        if regions is None or not regions.get("boxes"):
+                            logger.warning(f"No regions detected in {image_filename}")  # :50-52
+                            continue
+                        ids, metas, boxes, good = self._page_rows(image_path, regions)
+                        if not good:
+                            continue
+                        b = boxes[good]
+                        nbytes = int((((b[:, 3] - b[:, 1]).astype(np.int64) * (b[:, 2] - b[:, 0]) * 3 + 15) // 16 * 16).sum())
+                        if cur is not None and cur["pages"] and cur["base"] + nbytes > self.WAVE_BYTES:
+                            close_wave()
+                        if cur is None and not open_wave(nbytes):
+                            return
+                        if cur["base"] + nbytes + 16 > pipe["pix"][cur["slot"]].numel():  # an empty wave too small for this page
+                            slot_free[cur["slot"]].release()
+                            cur = None
+                            if not open_wave(nbytes):
+                                return
+                        try:
+                            with on(pipe["in_stream"]):
+                                page_dev = upload(arr, n_up)
+                                n_up += 1
+                                _, offs, hw = engine.crop_boxes(page_dev, b, out=pipe["pix"][cur["slot"]], base=cur["base"])
+                        except (MmeError, OSError, ValueError, RuntimeError) as e:
+                            logger.error(f"Error in batch processing: {e}")  # this page's regions fail, the wave goes on
+                            continue
+                        cur["pages"].append((image_path, ids, metas, good))
+                        cur["offs"].append(offs)
+                        cur["hw"].append(hw)
+                        cur["base"] += nbytes
+                        cur["crops"] += len(good)
+                        if cur["crops"] >= self.WAVE_CROPS:
+                            close_wave()
+                    close_wave()
+            except BaseException as e:  # never leave the consumer waiting
+                logger.error(f"Error in batch processing: {e}")
+                if cur is not None:
+                    slot_free[cur["slot"]].release()
+            finally:
+                ready.put(("end",))
+
+        total = 0
+        pending = None  # (slot, wave, n rows, device rows kept alive) whose D2H is in flight
+
+        def finalize(p):
+            nonlocal total
+            slot, wave, n, _keep = p
+            pipe["ev_out"][slot].synchronize()
+            rows = pipe["out"][slot][:n].numpy()
+            r0 = 0
+            for path, ids, metas, good in wave["pages"]:
+                emb = rows[r0: r0 + len(good)]
+                r0 += len(good)
+                total += self._upsert_page(os.path.basename(path), ids, metas, good, emb.tolist() if as_lists else list(emb.copy()))
+
+        producer = threading.Thread(target=produce, name="mme-region-stage", daemon=True)
+        producer.start()
+        try:
+            compute = t.cuda.current_stream(dev) if cuda else pipe["in_stream"]
+            while True:
+                msg = ready.get()
+                if msg[0] == "end":
+                    break
+                wave = msg[1]
+                slot = wave["slot"]
+                n = wave["crops"]
+                try:
+                    compute.wait_event(pipe["ev_ready"][slot])
+                    e32, _ = self.embedder.embed_packed(pipe["pix"][slot], np.concatenate(wave["offs"]), np.concatenate(wave["hw"]), want_bf16=False)
+                    pipe["ev_done"][slot].record(compute)
+                except (MmeError, OSError, ValueError, RuntimeError) as e:
+                    pipe["ev_done"][slot].record(compute)
+                    slot_free[slot].release()
+                    for path, *_ in wave["pages"]:
+                        logger.error(f"Error in batch processing: {e}")  # embedder.py:223-224, once per page the pass carried
+                    continue
+                slot_free[slot].release()  # the producer may refill the slot: its K0 launches wait for ev_done on the device
+                if pending is not None and pending[0] == slot:
+                    finalize(pending)
+                    pending = None
+                if pipe["out"][slot] is None or pipe["out"][slot].shape[0] < n or pipe["out"][slot].shape[1] != e32.shape[1]:
+                    pipe["out"][slot] = t.empty((max(n, 2048), e32.shape[1]), dtype=t.float32, pin_memory=cuda)
+                with on(pipe["out_stream"]):
+                    pipe["out_stream"].wait_event(pipe["ev_done"][slot])
+                    pipe["out"][slot][:n].copy_(e32, non_blocking=True)
+                    pipe["ev_out"][slot].record(pipe["out_stream"])
+                if pending is not None:
+                    finalize(pending)  # the previous wave's rows go to the store under this wave's device pass
+                pending = (slot, wave, n, e32)
+            if pending is not None:
+                finalize(pending)
+        except BaseException:
+            if cuda:
+                t.cuda.synchronize(dev)
+            raise
+        finally:
+            stop.set()
+            while producer.is_alive():  # drain so that a blocked put() returns
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            producer.join()
+        logger.info(f"Completed region processing: {total} regions processed in {total_images} images")
+        return total

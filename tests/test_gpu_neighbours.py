@@ -279,3 +279,59 @@ def test_collection_query_matches_the_reference_helper(engine, golden_dir):
     # an upsert invalidates the device copy of the table
     col.upsert(ids=["new"], embeddings=[g["queries"][0]], metadatas=[{"is_region": True}])
     assert col.query(query_embeddings=[g["queries"][0]], n_results=1)["ids"] == [["new"]]
+
+
+def test_create_cross_comparison_entry_point_matches_the_reference_picks(engine, golden_dir, tmp_path):
+    """`create_cross_comparison(embedder, collection, image_paths, top_n)` (cross_compare.py:19): the reference's own
+    entry point over a collection, against the picks the REAL function made on the same store (neighbour_cases.npz:
+    parsed from the HTML pages it wrote).  The store also holds region rows (no `image_path`: the reference skips them,
+    :163-166); one image is missing from the store and is re-embedded through the embedder (:94-106); an image whose
+    re-embedding fails is skipped."""
+    from multimodal_embeddings_amd.cross_compare import create_cross_comparison
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection
+
+    g = np.load(os.path.join(golden_dir, "neighbour_cases.npz"))
+    names = json.load(open(os.path.join(golden_dir, "neighbour_names.json")))["image_names"]
+    emb, want, want_d = g["image_emb"], g["image_idx"], g["image_distance_4dp"]
+    os.makedirs(tmp_path / "imgs")
+    paths = [str(tmp_path / "imgs" / nm) for nm in names]
+    for p in paths:
+        open(p, "w").close()  # candidates must exist on disk (:163-166)
+    col = RegionCollection(engine=engine)
+    missing = 11
+    keep = [r for r in range(len(names)) if r != missing]
+    col.add(ids=[f"image_{names[r]}" for r in keep], embeddings=[emb[r].tolist() for r in keep],
+            metadatas=[{"image_name": names[r], "image_path": paths[r], "is_region": False} for r in keep], documents=[f"Image: {names[r]}" for r in keep])
+    col.add(ids=["region_x_0", "region_x_1"], embeddings=[emb[0].tolist(), emb[20].tolist()],
+            metadatas=[{"is_region": True, "parent_image_name": "x"}] * 2, documents=[None, None])
+
+    class OneShotEmbedder:  # the reference's embedder contract: list in, list of float lists (or None holes) out
+        calls = []
+
+        def get_image_embeddings(self, image_paths, is_query=False, batch_size=16):
+            self.calls.append(list(image_paths))
+            return [emb[missing].tolist() if os.path.basename(p) == names[missing] else None for p in image_paths]
+
+    ghost = str(tmp_path / "imgs" / "Not In The Store.png")
+    out_json = tmp_path / "report" / "cross.json"
+    rep = create_cross_comparison(OneShotEmbedder(), col, paths + [ghost], output_path=str(out_json))
+    assert OneShotEmbedder.calls == [[paths[missing]], [ghost]]
+    assert [p["image"] for p in rep] == names  # the ghost got no page; order = image_paths order
+    assert col.get(ids=[f"image_{names[missing]}"])["metadatas"][0]["image_path"] == os.path.abspath(paths[missing])
+    doc = json.load(open(out_json))
+    assert doc["top_n"] == 5 and len(doc["images"]) == len(names)
+    same = total = 0
+    for r, page in enumerate(rep):
+        plen = max(1, int(len(names[r]) * 0.2))
+        got = [names.index(s["filename"]) for s in page["similar"]]
+        assert len(got) == 5 and r not in got and all(names[c][:plen] != names[r][:plen] for c in got)
+        assert all(not s["id"].startswith("region_") for s in page["similar"])
+        sc = [s["score"] for s in page["similar"]]
+        assert sc == sorted(sc)  # distances ascend
+        for c, d in zip(got, sc):
+            if c in want[r].tolist():
+                same += 1
+                k = want[r].tolist().index(c)
+                assert abs(d - want_d[r, k]) <= 6e-3  # bf16 rows at D = 64 against the f32 store of the golden run
+        total += int((want[r] >= 0).sum())
+    assert same / total > 0.93  # as test_image_report_through_reference_api: near-ties reorder under bf16 rounding

@@ -352,6 +352,38 @@ def test_c3_variable_size_crops_at_full_size(embedder, golden_dir):
     assert np.max(1.0 - np.sum(a32[sample].cpu().numpy() * want_emb, axis=1)) <= 1e-3
 
 
+def test_k1_is_bit_exact_on_every_bundled_crop_shape(embedder, golden_dir):
+    """K1's code path depends on (h, w) -- tap counts up to 2 * 72 + 1, up- or down-scaling per axis, the
+    eight-row / four-row / wide-crop launches of the horizontal pass, skipped passes when a side already fits -- so
+    EVERY one of the 1862 bundled crop shapes (the embedder's real input, region_processor.py:115-119; sizes in
+    tests/golden/bundled_crop_sizes_hw.npy, pixels seeded) is held to the oracle bit for bit, not a sample."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import preprocess as opre
+
+    sizes = np.load(os.path.join(golden_dir, "bundled_crop_sizes_hw.npy")).astype(np.int32)
+    n = len(sizes)
+    assert n == 1862
+    nbytes = sizes[:, 0].astype(np.int64) * sizes[:, 1] * 3
+    offs = np.zeros(n, dtype=np.int64)
+    offs[1:] = np.cumsum((nbytes[:-1] + 15) // 16 * 16)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    pix = torch.randint(0, 256, (int(offs[-1] + nbytes[-1]) + 16,), dtype=torch.uint8, device="cuda", generator=g)
+    got = embedder.engine.preprocess(pix, offs, sizes).view(torch.int16).cpu().numpy().reshape(n, 196, 768)
+    host = pix.cpu().numpy()
+    from multimodal_embeddings_amd.weights import f32_to_bf16_bits
+
+    def check(k):
+        h, w = sizes[k]
+        want = opre.preprocess_to_patches(host[offs[k] : offs[k] + nbytes[k]].reshape(h, w, 3))
+        return bool(np.array_equal(got[k].view(np.uint16), f32_to_bf16_bits(want)))
+
+    with ThreadPoolExecutor(max_workers=4) as ex:  # the oracle's passes are BLAS calls: they release the GIL
+        ok = list(ex.map(check, range(n)))
+    bad = [(int(sizes[k, 0]), int(sizes[k, 1])) for k in range(n) if not ok[k]]
+    assert not bad, f"{len(bad)} of {n} shapes differ from the oracle, first: {bad[:8]}"
+
+
 def test_page_matrix_pair_shards_add_up_to_the_single_gpu_matrix(embedder):
     """the upper-triangle page pairs split over 8 ranks (computed one after the other on this GPU):
     partial matrices are disjoint, their sum is the raw matrix bit for bit, and normalising the sum equals the

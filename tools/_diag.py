@@ -12,6 +12,7 @@ DIAG = os.path.join(ROOT, "multimodal_embeddings_amd", "libmme_diag.so")
 def use_diag_library(required: bool = True) -> bool:
     if os.path.exists(DIAG):
         os.environ["MME_LIB_PATH"] = DIAG
+        os.environ["MME_ALLOW_LIB_OVERRIDE"] = "1"  # _lib.load_library refuses MME_LIB_PATH without this opt-in
         return True
     if required:
         sys.exit(f"{DIAG} is missing: build it first (python -m multimodal_embeddings_amd.build --diag)")
