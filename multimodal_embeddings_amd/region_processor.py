@@ -107,6 +107,8 @@ class RegionProcessor:
     WAVE_CROPS = 1024       # crops a device pass of `process_regions` should carry at least (the encoder's rate per crop
     WAVE_BYTES = 1 << 30    # flattens out from ~1k crops per pass) ... and at most this many packed pixel bytes
     DECODE_AHEAD = 4        # pages decoded ahead of the device, on threads (Pillow releases the GIL while decoding)
+    WAVE_SLOTS = 3          # page arenas: one being cut on the device, one staged and waiting, one being uploaded
+    WAVE_PAGE_BYTES = 2 << 30  # page pixels a wave may hold on the device (pages of few boxes close a wave by this)
 
     def __init__(self, embedder, collection, detector=None):
         self.embedder, self.collection, self.detector = embedder, collection, detector
@@ -170,8 +172,9 @@ class RegionProcessor:
         return self._upsert_page(image_filename, ids, metas, good, emb)
 
     def _wave_pipe(self):
-        """Staging of `process_regions`, created once per processor: a copy stream (page uploads + K0), a result stream, two
-        pinned page buffers, one device page buffer, two packed-crop wave buffers and the events that order them."""
+        """Staging of `process_regions`, created once per processor: a copy stream for the page uploads, a result stream,
+        WAVE_SLOTS device arenas holding the pages of a wave, one packed-crop buffer, two pinned result buffers and the
+        events that order them."""
         if getattr(self, "_pipe", None) is None:
             from .embedder import _Null
 
@@ -179,10 +182,10 @@ class RegionProcessor:
             dev = t.device(self.embedder.device)
             cuda = dev.type == "cuda"
             mk_stream, mk_event = ((lambda: t.cuda.Stream(dev)), t.cuda.Event) if cuda else (_Null, _Null)
+            ns = max(2, int(self.WAVE_SLOTS))
             self._pipe = {"dev": dev, "cuda": cuda, "in_stream": mk_stream(), "out_stream": mk_stream(),
-                          "pin": [None, None], "ev_pin": [mk_event(), mk_event()], "pin_used": [False, False], "page_dev": None,
-                          "pix": [None, None], "ev_ready": [mk_event(), mk_event()], "ev_done": [mk_event(), mk_event()],
-                          "ev_out": [mk_event(), mk_event()], "out": [None, None], "slot_used": [False, False]}
+                          "arena": [None] * ns, "ev_cut": [mk_event() for _ in range(ns)], "slot_used": [False] * ns,
+                          "pix": None, "out": [None, None], "ev_pass": [mk_event(), mk_event()], "ev_out": [mk_event(), mk_event()]}
         return self._pipe
 
     def process_regions(self, image_paths, force_recompute=False, *, regions_by_path=None, pages=None, as_lists=True):
@@ -193,20 +196,25 @@ class RegionProcessor:
         call, :124-129) -- a device pass of this engine reaches its rate from ~1k crops on.  Here the boxes of SEVERAL
         pages fill one pass ("wave"), and the host side runs under the device passes:
           * pages are decoded ahead on threads (Pillow releases the GIL);
-          * a producer thread copies each page into one of two pinned buffers, uploads it on a copy stream and cuts its
-            boxes on the device (K0) straight into the wave's packed-crop buffer; a wave closes at >= WAVE_CROPS crops
-            (or WAVE_BYTES of pixels);
-          * this thread runs ONE `mme_embed` per wave, copies the rows back on a third stream and hands the rows of the
-            previous wave to the store -- per page, in page order, in the reference's chunks of REGION_BATCH_SIZE --
-            while the device works on the current one.
+          * a producer thread uploads the pages of a wave into one of WAVE_SLOTS device arenas on a copy stream (DMA: it
+            runs beside the encoder's kernels); a wave closes at >= WAVE_CROPS crops (or WAVE_BYTES of crop pixels, or
+            WAVE_PAGE_BYTES of page pixels);
+          * this thread cuts the boxes of the wave's pages on the device (K0, straight into the packed-crop buffer) and
+            runs ONE `mme_embed` over them -- both on the compute stream: a K0 launch of its own stream would wait for
+            a gap between the encoder's persistent kernels, page after page -- copies the rows back on a third stream
+            and hands the rows of the previous wave to the store -- per page, in page order, in the reference's chunks
+            of REGION_BATCH_SIZE -- while the device works on the current one.
         The contract per page is unchanged: an unreadable page is logged and skipped (`validate_image`, :43-45), a page
-        without regions is skipped with the reference's warning (:50-52), a page whose boxes cannot be cut or a failed
-        device pass voids exactly the pages concerned ("Error in batch processing"), a failed upsert voids its chunk.
+        without regions is skipped with the reference's warning (:50-52), a page whose boxes cannot be cut fails alone and
+        a failed device pass voids exactly the pages it carried ("Error in batch processing"), a failed upsert voids its
+        chunk.
 
         `regions_by_path` (path -> regions dict) replaces `detector.detect_regions`; `pages` (path -> decoded uint8
         [H, W, 3] array) replaces reading the file; `as_lists=False` upserts float32 ndarray rows instead of float lists."""
+        import contextlib
         import queue
         import threading
+        import time as _time
         from concurrent.futures import ThreadPoolExecutor
 
         from .embedder import _load_rgb
@@ -215,9 +223,16 @@ class RegionProcessor:
         engine = self.embedder.engine
         pipe = self._wave_pipe()
         dev, cuda = pipe["dev"], pipe["cuda"]
+        ns = len(pipe["arena"])
         total_images = len(image_paths)
         logger.info(f"Processing regions for {total_images} images")
-        on = (lambda stream: t.cuda.stream(stream)) if cuda else (lambda stream: __import__("contextlib").nullcontext())
+        on = (lambda stream: t.cuda.stream(stream)) if cuda else (lambda stream: contextlib.nullcontext())
+        trace = getattr(self, "trace", None)  # tools: a dict of accumulated seconds per stage of the two threads
+
+        def tick(key, t0):
+            if trace is not None:
+                trace[key] = trace.get(key, 0.0) + (_time.perf_counter() - t0)
+            return _time.perf_counter()
 
         def decode(path):
             try:
@@ -228,60 +243,25 @@ class RegionProcessor:
                 logger.error(f"Invalid image file {path}: {e}")
                 return None
 
-        def upload(arr, k):
-            """Page pixels -> the device page buffer, through pinned slot k & 1 (the copy into the pinned buffer of page
-            k + 1 runs while the DMA of page k is in flight)."""
-            arr = np.require(arr, requirements=["C"])
-            nb = arr.nbytes
-            s = k & 1
-            if pipe["pin"][s] is None or pipe["pin"][s].numel() < nb:
-                if pipe["pin_used"][s]:
-                    pipe["ev_pin"][s].synchronize()
-                pipe["pin"][s] = t.empty(max(nb, 1 << 24), dtype=t.uint8, pin_memory=cuda)
-            elif pipe["pin_used"][s]:
-                pipe["ev_pin"][s].synchronize()  # the DMA that last read this pinned buffer has finished
-            pipe["pin_used"][s] = True
-            hv = pipe["pin"][s].numpy()
-            flat = arr.reshape(-1)
-            workers = min(4, os.cpu_count() or 1, max(1, nb >> 25))  # large numpy copies release the GIL
-            if workers > 1:
-                cuts = [nb * w // workers for w in range(workers + 1)]
-                with ThreadPoolExecutor(max_workers=workers) as pool:
-                    list(pool.map(lambda ab: hv.__setitem__(slice(ab[0], ab[1]), flat[ab[0]: ab[1]]), zip(cuts[:-1], cuts[1:])))
-            else:
-                hv[:nb] = flat
-            with on(pipe["in_stream"]):
-                if pipe["page_dev"] is None or pipe["page_dev"].numel() < nb:
-                    pipe["page_dev"] = t.empty(max(nb, 1 << 24), dtype=t.uint8, device=dev)  # same stream as its readers: ordered
-                pipe["page_dev"][:nb].copy_(pipe["pin"][s][:nb], non_blocking=True)
-                pipe["ev_pin"][s].record(pipe["in_stream"])
-            return pipe["page_dev"][:nb].view(arr.shape)
-
-        ready = queue.Queue(maxsize=2)
-        slot_free = [threading.Semaphore(1), threading.Semaphore(1)]
+        ready = queue.Queue(maxsize=ns)
+        slot_free = [threading.Semaphore(1) for _ in range(ns)]
         stop = threading.Event()
 
         def produce():
-            wave_no, n_up = 0, 0
-            cur = None  # open wave: {"slot", "pages": [(path, ids, metas, good)], "offs": [...], "hw": [...], "base", "crops"}
+            wave_no = 0
+            cur = None  # open wave: {"slot", "pages": [(path, ids, metas, good, boxes, arena offset, shape)], "crops", "crop_bytes", "page_bytes"}
 
-            def open_wave(min_bytes):
+            def open_wave():
                 nonlocal cur
-                slot = wave_no & 1
+                slot = wave_no % ns
                 while not slot_free[slot].acquire(timeout=0.1):
                     if stop.is_set():
                         return False
-                need = max(self.WAVE_BYTES, min_bytes) + 16
-                if pipe["pix"][slot] is None or pipe["pix"][slot].numel() < need:
-                    if pipe["slot_used"][slot]:
-                        pipe["ev_done"][slot].synchronize()  # the pass that read the old buffer has run
-                    with on(pipe["in_stream"]):
-                        pipe["pix"][slot] = t.empty(need, dtype=t.uint8, device=dev)
                 if pipe["slot_used"][slot]:
                     with on(pipe["in_stream"]):
-                        pipe["in_stream"].wait_event(pipe["ev_done"][slot])
+                        pipe["in_stream"].wait_event(pipe["ev_cut"][slot])  # the K0 launches that read this arena have run
                 pipe["slot_used"][slot] = True
-                cur = {"slot": slot, "pages": [], "offs": [], "hw": [], "base": 0, "crops": 0}
+                cur = {"slot": slot, "pages": [], "crops": 0, "crop_bytes": 0, "page_bytes": 0}
                 return True
 
             def close_wave():
@@ -289,13 +269,32 @@ class RegionProcessor:
                 if cur is None:
                     return
                 if cur["pages"]:
-                    with on(pipe["in_stream"]):
-                        pipe["ev_ready"][cur["slot"]].record(pipe["in_stream"])
-                    ready.put(("wave", cur))
+                    ready.put(("wave", cur))  # every upload of the wave has completed: the copies below are blocking
                     wave_no += 1
                 else:
                     slot_free[cur["slot"]].release()
                 cur = None
+
+            def upload(arr, slot, at):
+                """Page pixels -> the wave's arena at byte `at`, straight from the decoded (pageable) array: on this platform
+                the driver's own staging moves pageable memory at the pinned rate, idle or beside the encoder
+                (tools/host_copy_probe.py: 56 GB/s), so a pinned copy in front of the DMA would only cost a pass over host
+                memory.  Returns when the copy has been made."""
+                arr = np.require(arr, requirements=["C"])
+                nb = arr.nbytes
+                arena = pipe["arena"][slot]
+                if arena is None or arena.numel() < at + nb:
+                    grown = t.empty(max(at + nb, self.WAVE_PAGE_BYTES // 2, 1 << 24), dtype=t.uint8, device=dev)
+                    if arena is not None:
+                        if at:  # pages of this wave already sit in the old arena
+                            with on(pipe["in_stream"]):
+                                grown[:at].copy_(arena[:at])
+                                pipe["in_stream"].synchronize()
+                        pipe["ev_cut"][slot].synchronize()  # nothing reads the old arena any more
+                    pipe["arena"][slot] = arena = grown
+                with on(pipe["in_stream"]):
+                    arena[at : at + nb].copy_(t.from_numpy(arr.reshape(-1)))
+                return nb
 
             try:
                 with ThreadPoolExecutor(max_workers=self.DECODE_AHEAD) as pool:
@@ -303,7 +302,9 @@ class RegionProcessor:
                     for idx, image_path in enumerate(image_paths):
                         if stop.is_set():
                             return
+                        tk = _time.perf_counter()
                         arr = futures.pop(idx).result()
+                        tk = tick("producer: wait for decode", tk)
                         if idx + self.DECODE_AHEAD < total_images:
                             futures[idx + self.DECODE_AHEAD] = pool.submit(decode, image_paths[idx + self.DECODE_AHEAD])
                         if (idx + 1) % 5 == 0 or idx == total_images - 1:
@@ -321,31 +322,31 @@ class RegionProcessor:
                             logger.warning(f"No regions detected in {image_filename}")  # :50-52
                             continue
                         ids, metas, boxes, good = self._page_rows(image_path, regions)
+                        tk = tick("producer: rows", tk)
                         if not good:
                             continue
                         b = boxes[good]
-                        nbytes = int((((b[:, 3] - b[:, 1]).astype(np.int64) * (b[:, 2] - b[:, 0]) * 3 + 15) // 16 * 16).sum())
-                        if cur is not None and cur["pages"] and cur["base"] + nbytes > self.WAVE_BYTES:
+                        side = np.stack([b[:, 3] - b[:, 1], b[:, 2] - b[:, 0]], axis=1)
+                        if side.max() > 8000:  # mme_crop_boxes' limit (the embedder's own 8000-px cap, embedder.py:110-114)
+                            logger.error(f"Error in batch processing: a region of {image_filename} is {int(side.max())} px long (supported: 8000)")
+                            continue
+                        nbytes = int(((side[:, 0].astype(np.int64) * side[:, 1] * 3 + 15) // 16 * 16).sum())
+                        if cur is not None and cur["pages"] and (cur["crop_bytes"] + nbytes > self.WAVE_BYTES
+                                                                 or cur["page_bytes"] + arr.nbytes > self.WAVE_PAGE_BYTES):
                             close_wave()
-                        if cur is None and not open_wave(nbytes):
+                        if cur is None and not open_wave():
                             return
-                        if cur["base"] + nbytes + 16 > pipe["pix"][cur["slot"]].numel():  # an empty wave too small for this page
-                            slot_free[cur["slot"]].release()
-                            cur = None
-                            if not open_wave(nbytes):
-                                return
+                        tk = tick("producer: wait for a wave slot", tk)
                         try:
-                            with on(pipe["in_stream"]):
-                                page_dev = upload(arr, n_up)
-                                n_up += 1
-                                _, offs, hw = engine.crop_boxes(page_dev, b, out=pipe["pix"][cur["slot"]], base=cur["base"])
-                        except (MmeError, OSError, ValueError, RuntimeError) as e:
+                            at = (cur["page_bytes"] + 255) // 256 * 256
+                            nb = upload(arr, cur["slot"], at)
+                        except (OSError, ValueError, RuntimeError) as e:
                             logger.error(f"Error in batch processing: {e}")  # this page's regions fail, the wave goes on
                             continue
-                        cur["pages"].append((image_path, ids, metas, good))
-                        cur["offs"].append(offs)
-                        cur["hw"].append(hw)
-                        cur["base"] += nbytes
+                        tk = tick("producer: page H2D", tk)
+                        cur["pages"].append((image_path, ids, metas, good, b, at, arr.shape))
+                        cur["page_bytes"] = at + nb
+                        cur["crop_bytes"] += nbytes
                         cur["crops"] += len(good)
                         if cur["crops"] >= self.WAVE_CROPS:
                             close_wave()
@@ -358,15 +359,16 @@ class RegionProcessor:
                 ready.put(("end",))
 
         total = 0
-        pending = None  # (slot, wave, n rows, device rows kept alive) whose D2H is in flight
+        pending = None  # (result slot, wave, n rows, device rows kept alive) whose D2H is in flight
+        n_pass = 0
 
         def finalize(p):
             nonlocal total
-            slot, wave, n, _keep = p
-            pipe["ev_out"][slot].synchronize()
-            rows = pipe["out"][slot][:n].numpy()
+            rs, wave, n, _keep = p
+            pipe["ev_out"][rs].synchronize()
+            rows = pipe["out"][rs][:n].numpy()
             r0 = 0
-            for path, ids, metas, good in wave["pages"]:
+            for path, ids, metas, good, *_ in wave["pages"]:
                 emb = rows[r0: r0 + len(good)]
                 r0 += len(good)
                 total += self._upsert_page(os.path.basename(path), ids, metas, good, emb.tolist() if as_lists else list(emb.copy()))
@@ -376,35 +378,64 @@ class RegionProcessor:
         try:
             compute = t.cuda.current_stream(dev) if cuda else pipe["in_stream"]
             while True:
+                tk = _time.perf_counter()
                 msg = ready.get()
+                tk = tick("consumer: wait for a staged wave", tk)
                 if msg[0] == "end":
                     break
                 wave = msg[1]
                 slot = wave["slot"]
-                n = wave["crops"]
                 try:
-                    compute.wait_event(pipe["ev_ready"][slot])
-                    e32, _ = self.embedder.embed_packed(pipe["pix"][slot], np.concatenate(wave["offs"]), np.concatenate(wave["hw"]), want_bf16=False)
-                    pipe["ev_done"][slot].record(compute)
+                    need = wave["crop_bytes"] + 16
+                    if pipe["pix"] is None or pipe["pix"].numel() < need:
+                        pipe["pix"] = t.empty(max(need, self.WAVE_BYTES // 4), dtype=t.uint8, device=dev)  # compute stream: ordered with its readers
+                    offs_all, hw_all, base, kept = [], [], 0, []
+                    for page in wave["pages"]:
+                        path, ids, metas, good, b, at, shape = page
+                        nb = int(shape[0]) * int(shape[1]) * int(shape[2])
+                        try:
+                            _, offs, hw = engine.crop_boxes(pipe["arena"][slot][at : at + nb].view(shape), b, out=pipe["pix"], base=base)
+                        except (MmeError, ValueError) as e:
+                            logger.error(f"Error in batch processing: {e}")  # this page's regions fail, the wave goes on
+                            continue
+                        offs_all.append(offs)
+                        hw_all.append(hw)
+                        base = int(offs[-1]) + (int(hw[-1, 0]) * int(hw[-1, 1]) * 3 + 15) // 16 * 16
+                        kept.append(page)
+                    wave["pages"] = kept
+                    pipe["ev_cut"][slot].record(compute)
+                    slot_free[slot].release()  # the producer may refill the arena: its copies wait for ev_cut on the device
+                    slot = None
+                    tk = tick("consumer: crop_boxes calls", tk)
+                    if not kept:
+                        continue
+                    n = sum(len(o) for o in offs_all)
+                    e32, _ = self.embedder.embed_packed(pipe["pix"], np.concatenate(offs_all), np.concatenate(hw_all), want_bf16=False)
+                    tk = tick("consumer: embed call", tk)
                 except (MmeError, OSError, ValueError, RuntimeError) as e:
-                    pipe["ev_done"][slot].record(compute)
-                    slot_free[slot].release()
+                    if slot is not None:
+                        pipe["ev_cut"][slot].record(compute)
+                        slot_free[slot].release()
                     for path, *_ in wave["pages"]:
                         logger.error(f"Error in batch processing: {e}")  # embedder.py:223-224, once per page the pass carried
                     continue
-                slot_free[slot].release()  # the producer may refill the slot: its K0 launches wait for ev_done on the device
-                if pending is not None and pending[0] == slot:
-                    finalize(pending)
+                rs = n_pass & 1
+                n_pass += 1
+                pipe["ev_pass"][rs].record(compute)
+                if pending is not None and pending[0] == rs:
+                    finalize(pending)  # the result buffer is about to be reused
                     pending = None
-                if pipe["out"][slot] is None or pipe["out"][slot].shape[0] < n or pipe["out"][slot].shape[1] != e32.shape[1]:
-                    pipe["out"][slot] = t.empty((max(n, 2048), e32.shape[1]), dtype=t.float32, pin_memory=cuda)
+                if pipe["out"][rs] is None or pipe["out"][rs].shape[0] < n or pipe["out"][rs].shape[1] != e32.shape[1]:
+                    pipe["out"][rs] = t.empty((max(n, 2048), e32.shape[1]), dtype=t.float32, pin_memory=cuda)
                 with on(pipe["out_stream"]):
-                    pipe["out_stream"].wait_event(pipe["ev_done"][slot])
-                    pipe["out"][slot][:n].copy_(e32, non_blocking=True)
-                    pipe["ev_out"][slot].record(pipe["out_stream"])
+                    pipe["out_stream"].wait_event(pipe["ev_pass"][rs])
+                    pipe["out"][rs][:n].copy_(e32, non_blocking=True)
+                    pipe["ev_out"][rs].record(pipe["out_stream"])
+                tk = _time.perf_counter()
                 if pending is not None:
                     finalize(pending)  # the previous wave's rows go to the store under this wave's device pass
-                pending = (slot, wave, n, e32)
+                tick("consumer: rows of the previous wave to the store", tk)
+                pending = (rs, wave, n, e32)
             if pending is not None:
                 finalize(pending)
         except BaseException:

@@ -572,3 +572,106 @@ def test_create_cross_comparison_host_logic_equals_the_reference_picks_exactly(g
         assert [f"{s['score']:.4f}" for s in page["similar"]] == [f"{d:.4f}" for d in g["image_distance_4dp"][r][: len(want)]]
     # a path that is not in the store and cannot be embedded (no embedder) is skipped, as :94-106
     assert create_cross_comparison(None, Store(), [str(tmp_path / "ghost.png")]) == []
+
+
+def test_process_regions_wave_logic_without_a_device():
+    """Host side of RegionProcessor.process_regions (region_processor.py:36-60 mirror) with a stand-in engine on CPU
+    tensors: waves close at WAVE_CROPS / WAVE_BYTES, rows reach the store per page in page order and in chunks of
+    REGION_BATCH_SIZE, a failing device pass voids exactly the pages it carried, a page whose boxes cannot be cut fails
+    alone, unreadable and region-less pages are skipped."""
+    import torch
+
+    from multimodal_embeddings_amd import config
+    from multimodal_embeddings_amd._lib import MmeError
+    from multimodal_embeddings_amd.region_processor import RegionProcessor
+
+    class FakeEngine:
+        device = 0
+
+        def crop_boxes(self, page, boxes, out=None, base=0):
+            b = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
+            hw = np.stack([b[:, 3] - b[:, 1], b[:, 2] - b[:, 0]], axis=1).astype(np.int32)
+            if hw.max() > 100:
+                raise MmeError("box too large (simulated)")
+            size = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+            offs = np.zeros(len(b), dtype=np.int64)
+            offs[1:] = np.cumsum((size[:-1] + 15) // 16 * 16)
+            offs += base
+            for (x0, y0, x1, y1), o, sz in zip(b, offs, size):
+                out[o : o + sz] = page[y0:y1, x0:x1].reshape(-1)
+            return out, offs, hw
+
+    _torch = torch
+
+    class FakeEmbedder:
+        torch = _torch
+        device = _torch.device("cpu")
+        engine = FakeEngine()
+        passes = []
+        fail_pass = None
+
+        def embed_packed(self, pix, offs, hw, want_bf16=False):
+            self.passes.append(len(offs))
+            if self.fail_pass is not None and len(self.passes) - 1 == self.fail_pass:
+                raise MmeError("out of memory (simulated)")
+            first = pix[torch.from_numpy(offs)].float()  # "embedding" = (first byte of the crop, height, width)
+            return torch.stack([first, torch.from_numpy(hw[:, 0]).float(), torch.from_numpy(hw[:, 1]).float()], dim=1), None
+
+    class Store:
+        def __init__(self):
+            self.rows, self.calls = [], []
+
+        def upsert(self, ids, embeddings, documents=None, metadatas=None):
+            self.calls.append((metadatas[0]["parent_image_name"], len(ids)))
+            self.rows += list(zip(ids, embeddings))
+
+    rng = np.random.default_rng(0)
+
+    def make_page(k, n):
+        page = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+        boxes = []
+        for _ in range(n):
+            x0, y0 = int(rng.integers(0, 100)), int(rng.integers(0, 80))
+            boxes.append([x0 + 0.3, y0 + 0.7, x0 + int(rng.integers(2, 50)) + 0.9, y0 + int(rng.integers(2, 30)) + 0.2])
+        regions = {"boxes": boxes, "classes": [1.0] * n, "class_names": ["plain_text"] * n, "scores": [0.5] * n, "image_size": {"width": 160, "height": 120}}
+        return f"/pages/page {k:02d}.png", page, regions
+
+    specs = [make_page(k, n) for k, n in enumerate([60, 5, 70, 3, 130, 8])]
+    pages = {p: a for p, a, _ in specs}
+    regs = {p: r for p, _, r in specs}
+    regs["/pages/none.png"] = {"boxes": []}
+    pages["/pages/none.png"] = np.zeros((8, 8, 3), np.uint8)
+    regs["/pages/big.png"] = {"boxes": [[0, 0, 150, 10]], "classes": [1.0], "class_names": ["title"], "scores": [1.0], "image_size": {"width": 160, "height": 120}}
+    pages["/pages/big.png"] = np.zeros((120, 160, 3), np.uint8)
+    order = [specs[0][0], "/pages/missing.png", specs[1][0], "/pages/none.png", specs[2][0], "/pages/big.png", specs[3][0], specs[4][0], specs[5][0]]
+    regs["/pages/missing.png"] = specs[0][2]  # regions known, pixels unreadable
+
+    def run(fail_pass=None, wave=64):
+        emb, store = FakeEmbedder(), Store()
+        emb.passes, emb.fail_pass = [], fail_pass
+        rp = RegionProcessor(emb, store)
+        rp.WAVE_CROPS = wave
+        n = rp.process_regions(order, regions_by_path=regs, pages=pages)
+        return n, emb, store
+
+    n, emb, store = run()
+    assert n == 60 + 5 + 70 + 3 + 130 + 8 == len(store.rows)
+    assert emb.passes == [65, 70, 133, 8]  # waves close once >= 64 crops are in, whole pages only
+    assert [c for c in store.calls if c[0] == "page 04.png"] == [("page 04.png", 48), ("page 04.png", 48), ("page 04.png", 34)]
+    names = [c[0] for c in store.calls]
+    assert sorted(set(names), key=names.index) == [os.path.basename(s[0]) for s in specs]  # page order, big / none / missing absent
+    # every row is the crop the reference's int() rule cuts: first byte, height, width
+    k = 0
+    for path, page, r in specs:
+        for i, box in enumerate(r["boxes"]):
+            x0, y0, x1, y1 = map(int, box)
+            rid, vec = store.rows[k]
+            assert rid == f"region_{os.path.splitext(os.path.basename(path))[0]}_{i}" and vec == [float(page[y0, x0, 0]), float(y1 - y0), float(x1 - x0)]
+            k += 1
+    assert all(cnt <= config.REGION_BATCH_SIZE for _, cnt in store.calls)
+    # the second device pass fails: exactly its page (page 02) is missing, everything else arrives
+    n2, emb2, store2 = run(fail_pass=1)
+    assert n2 == n - 70 and "page 02.png" not in [c[0] for c in store2.calls] and emb2.passes == [65, 70, 133, 8]
+    # one wave for everything when the threshold is large; a byte cap closes waves too
+    n3, emb3, _ = run(wave=10_000)
+    assert n3 == n and emb3.passes == [276]
