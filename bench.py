@@ -70,7 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", choices=["auto", "c2", "c3", "c4", "c5"], default="auto", help="auto: c2 on one GPU, c4 on several")
+    ap.add_argument("--config", choices=["auto", "c2", "c3", "c4", "c5", "tilevit"], default="auto",
+                    help="auto: c2 on one GPU, c4 on several; tilevit: SURVEY 8f-2, the Mllama vision tower geometry on four-tile crops")
     ap.add_argument("--crops", type=int, default=0, help="crops per GPU (overrides the config's 4096 / 8192)")
     ap.add_argument("--table-rows", type=int, default=-1, help="rows of the table the cosine block runs against "
                     "(-1: by config; rows beyond the gathered shards are seeded synthetic unit rows)")
@@ -301,6 +302,8 @@ def main():
 
     rank, world, local = mdist.init_from_env(force=args.force_dist)
     use_dist = mdist.collectives_active()  # world > 1, or the forced process group of one rank
+    if args.config == "tilevit":
+        return main_tilevit(args, rank, world, local, use_dist)
     if world != args.gpus:
         if rank == 0:
             print(f"error: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, or run "
@@ -597,6 +600,122 @@ def main():
             "cpu_crops_per_s": out.get("cpu_baseline", {}).get("value"), "cpu_cores": out.get("cpu_baseline", {}).get("cores"),
             "max_cosine_error_vs_cpu_ref": parity, "labels_equal_oracle": labels_equal,
         }
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+TILE_TOKENS = 4 * 1608  # one crop = ONE sequence of 4 tiles x 1608 tokens (padding tiles and tokens included: the model attends to them)
+FLOP_TILE_ATTN_PER_LAUNCH_PER_CROP = 4 * TILE_TOKENS * TILE_TOKENS * 1280  # QK^T + PV of the 16 heads of one layer
+FLOP_TILE_GEMM_PER_CROP = 40 * 2 * TILE_TOKENS * (1280 * 3840 + 1280 * 1280 + 2 * 1280 * 5120) + 2 * 6400 * 588 * 1280
+FLOP_TILE_PER_CROP = 40 * FLOP_TILE_ATTN_PER_LAUNCH_PER_CROP + FLOP_TILE_GEMM_PER_CROP
+
+
+def main_tilevit(args, rank, world, local, use_dist):
+    """`--config tilevit`: four-tile crops through `mme_tile_vit_forward` -- the reference checkpoint's own
+    vision-tower geometry (transformers `MllamaVisionModel` at image 560: 32 local + 8 gated global layers, 1280-d, 16
+    heads of 80, one sequence of 6432 tokens per crop) on seeded synthetic weights.  A step = one pass over this rank's
+    crops, pixel values resident; ranks are replicas (crops are independent, no collective).  `roofline` is the attention
+    kernel `attn_fwd_tiles` (the largest class of the pass); `roofline_gemm` the GEMM launches; `cpu_baseline` the oracle
+    (oracle/mllama_vision.py, torch-CPU f32) on ONE crop through 4 local + 1 global layers, scaled to 32 + 8."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from multimodal_embeddings_amd import dist as mdist
+    from multimodal_embeddings_amd._lib import Engine
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+    from multimodal_embeddings_amd.weights import TileViTGeometry, make_tile_vit_weights
+
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    n = args.crops or 8
+    w = make_tile_vit_weights(2)
+    eng = Engine(local)
+    eng.load_tile_vit(w)
+    rng = np.random.default_rng(rank)
+    arrays = [rng.integers(0, 256, (1000 + 7 * k, 1100, 3), dtype=np.uint8) for k in range(n)]  # every crop fits the 2 x 2 tile grid
+    emb = RegionEmbedder(engine=eng)
+    pix, offs, hw = emb.pack(arrays, dev)
+    pv, ids, _, nt = eng.preprocess_tiles(pix, offs, hw, 560, 4)
+    assert all(int(v) == 4 for v in nt)
+    eng.set_chunk(n)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        eng.tile_vit_forward(pv, ids, nt)
+    fence()
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, e32, _ = eng.tile_vit_forward(pv, ids, nt)
+    fence()
+    elapsed_local = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile(False)
+    per_rank = mdist.all_gather_floats(elapsed_local, dev)
+    elapsed = max(per_rank)
+    steps = max(args.steps, 1)
+    if rank == 0:
+        att_ms, att_l = prof["attention"]
+        gemm_ms, gemm_l = prof["gemm"]
+        ach_att = FLOP_TILE_ATTN_PER_LAUNCH_PER_CROP * n * att_l / (att_ms * 1e-3) / 1e12 if att_ms > 0 else None
+        ach_gemm = FLOP_TILE_GEMM_PER_CROP * n * steps / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+        out = {
+            "metric": baseline_metric_name(), "value": n * world * steps / elapsed, "unit": "region-crops/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"TILEVIT: {n} four-tile crops (1000..1049 x 1100 px -> 2 x 2 tiles of 560 x 560) per GPU through the Mllama vision "
+                                   "tower geometry (32 local + 8 gated global layers, 1280-d, 16 heads of 80, 6432 tokens per crop, 7680-d output); "
+                                   "pixel values resident; seeded synthetic weights",
+                       "name": "tilevit", "crops_per_gpu": n, "parallelism": f"replicas x{world} (no collective)" if world > 1 else "single GPU",
+                       "note": "SURVEY.md 8f-2 (the reference checkpoint's own encoder geometry); NOT the configuration BASELINE.json's metric is "
+                               "quoted on (that is ViT-B/16 at 224 x 224, the default line)"},
+            "ms_per_step_by_rank": [t * 1e3 / steps for t in per_rank],
+            "forward_tflops": FLOP_TILE_PER_CROP * n * steps / elapsed_local / 1e12,
+            "forward_mfma_frac": FLOP_TILE_PER_CROP * n * steps / elapsed_local / (MFMA_BF16_PEAK_TFLOPS * 1e12),
+            "flop_per_crop": FLOP_TILE_PER_CROP,
+            "kernel_ms_per_step": {k: v[0] / steps for k, v in prof.items() if v[1]},
+            "roofline": {"kernel": "attn_fwd_tiles (self-attention of one layer over 6432-token sequences, 16 heads of 80)", "bound": "mfma",
+                         "achieved": ach_att, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_att / MFMA_BF16_PEAK_TFLOPS if ach_att else None,
+                         "traffic": None, "launches_per_step": att_l / steps, "avg_launch_ms": att_ms / att_l if att_l else None,
+                         "flop_per_launch": FLOP_TILE_ATTN_PER_LAUNCH_PER_CROP * n,
+                         "note": "algorithmic FLOP = 4 T^2 d per layer and crop (QK^T and PV at the real head dim 80; the zero-padded third value block "
+                                 "the kernel multiplies is not counted); duration = HIP events around every launch on the launch stream"},
+            "roofline_gemm": {"kernel": "gemm_bf16_tn_256r (patch, QKV, o_proj, fc1, fc2 launches of the tower)", "bound": "mfma", "achieved": ach_gemm,
+                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_gemm / MFMA_BF16_PEAK_TFLOPS if ach_gemm else None,
+                              "launches_per_step": gemm_l / steps, "avg_launch_ms": gemm_ms / gemm_l if gemm_l else None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import mllama_vision as omv
+
+            torch.set_num_threads(min(os.cpu_count() or 1, 16))
+            shallow = TileViTGeometry(num_layers=4, num_global_layers=1, intermediate_layers=(1, 3))
+            t1 = time.perf_counter()
+            want = omv.vision_forward(pv[0].cpu().numpy(), int(ids[0]), int(nt[0]), w, shallow)
+            dt = time.perf_counter() - t1
+            scale = 40.0 / 5.0
+            out["cpu_baseline"] = {"value": 1.0 / (dt * scale), "unit": "region-crops/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"1 four-tile crop through 4 local + 1 global layers of the oracle (torch-CPU f32), {dt:.1f} s, scaled x{scale:g} "
+                                             "to the 32 + 8 layers of the tower (layers cost the same)", "seconds_sample": dt}
+            # the same shallow stack on the GPU against that oracle run (the checker, on the sample it just produced)
+            eng2 = Engine(local)
+            eng2.load_tile_vit(w, shallow)
+            hid, _, _ = eng2.tile_vit_forward(pv[:1], ids[:1], nt[:1], want_hidden=True)
+            got = hid[0].cpu().numpy().reshape(-1, want.shape[-1]).astype(np.float64)
+            ref = want.reshape(-1, want.shape[-1]).astype(np.float64)
+            cos = np.sum(got * ref, axis=1) / np.maximum(np.linalg.norm(got, axis=1) * np.linalg.norm(ref, axis=1), 1e-30)
+            out["parity_min_token_cosine_vs_oracle"] = float(cos.min())
+            eng2.close()
+        out["table_row"] = {"config": "TILEVIT", "gpus": world, "crops_per_s": out["value"], "forward_tflops": out["forward_tflops"],
+                            "forward_pct_of_2p5pf": 100.0 * out["forward_mfma_frac"], "cpu_crops_per_s": out.get("cpu_baseline", {}).get("value"),
+                            "cpu_cores": out.get("cpu_baseline", {}).get("cores")}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

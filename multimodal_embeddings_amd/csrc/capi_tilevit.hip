@@ -118,7 +118,12 @@ int mme_load_tile_vit(mme_ctx* c, const mme_tile_vit_weights* w) {
         TileLayerDev& Ld = t->layer[l];
         // x + tanh(gate) * branch(x): the gate multiplies the branch's LAST linear map (global layers only)
         const float ga = a.gated ? std::tanh(a.gate_attn) : 1.0f, gf = a.gated ? std::tanh(a.gate_ffn) : 1.0f;
-        const float* qkv[3] = {a.q_w, a.k_w, a.v_w};
+        // The attention kernels take their scores in log2 units straight from the matrix pipe (attention_tiles.hip): 80^-0.5 * log2(e)
+        // is folded into the query projection here, once, BEFORE the rounding to bf16 that the upload applies anyway (as mme_load_vit does)
+        const float qsc = 0.11180339887498949f * 1.44269504088896341f;
+        std::vector<float> qw_s((size_t)TD * TD);
+        for (size_t i = 0; i < qw_s.size(); ++i) qw_s[i] = a.q_w[i] * qsc;
+        const float* qkv[3] = {qw_s.data(), a.k_w, a.v_w};
         const float* nob[3] = {nullptr, nullptr, nullptr};
         const size_t r3[3] = {TD, TD, TD};
         if ((r = upload_folded(c, qkv, nob, r3, 3, TD, a.ln1_g, a.ln1_b, &Ld.qkv_wf, &Ld.qkv_cs, &Ld.qkv_bf))) return r;
@@ -175,6 +180,12 @@ int mme_tile_vit_forward(mme_ctx* c, const float* pixel_values, const int32_t* a
         int32_t* nt_dev = aid_dev + t->ws_images;
         HIP_TRY(c, hipMemcpyAsync(aid_dev, aspect_ids_host + i0, (size_t)m * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(nt_dev, num_tiles_host + i0, (size_t)m * 4, hipMemcpyHostToDevice, s));
+        // one guard word per layer for the fast attention form (attention_tiles.hip): zeroed per pass
+        {
+            int rg;
+            if ((rg = ensure(c, c->attn_guard, 64 * sizeof(int)))) return rg;
+        }
+        if (c->attn_mode) HIP_TRY(c, hipMemsetAsync(c->attn_guard.p, 0, 64 * sizeof(int), s));
         const int64_t npatch = (int64_t)m * TTILES * TGRID * TGRID;
         {
             Timed tm(c, s, KC_PRE);
@@ -232,7 +243,7 @@ int mme_tile_vit_forward(mme_ctx* c, const float* pixel_values, const int32_t* a
             }
             {
                 Timed tm(c, s, KC_ATTN);
-                HIP_TRY(c, launch_attention_tiles(t->qkv.p, t->att.p, nt_dev, m, s));
+                HIP_TRY(c, launch_attention_tiles(t->qkv.p, t->att.p, nt_dev, m, s, c->attn_mode ? (int*)c->attn_guard.p + l : nullptr, c->attn_mode == 2));
             }
             {
                 Timed tm(c, s, KC_GEMM);

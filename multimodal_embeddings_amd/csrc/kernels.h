@@ -213,4 +213,4 @@ hipError_t launch_tile_assemble(const void* pemb, const float* cls, const float*
 hipError_t launch_tile_ln_post(void* x, const float* g, const float* b, const float* post, const int32_t* aid, int64_t rows, float eps, hipStream_t s);
 hipError_t launch_tile_output(const void* x, const void* inter, int ni, int64_t inter_stride, float* hidden, int64_t out_rows, hipStream_t s);
 hipError_t launch_tile_pool(const void* x, const void* inter, int ni, int64_t inter_stride, int n, float* emb_f32, void* emb_bf16, hipStream_t s);
-hipError_t launch_attention_tiles(const void* qkv, void* out, const int32_t* ntiles_dev, int n, hipStream_t s);
+hipError_t launch_attention_tiles(const void* qkv, void* out, const int32_t* ntiles_dev, int n, hipStream_t s, int* guard = nullptr, bool force_redo = false);
