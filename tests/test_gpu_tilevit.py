@@ -151,6 +151,49 @@ def test_peaked_attention_moves_the_running_maximum_mid_sequence():
     eng.close()
 
 
+def test_fast_attention_form_tracks_its_range_and_falls_back_to_the_exact_kernel():
+    """The default attention launch of the option is the FAST form (attention_tiles.hip: reference point inside the matrix
+    pipe, row sums from a ones column beside V, the reference re-centred from the row sum instead of a running maximum)
+    followed by the exact kernel, which runs only when a row of the fast launch left its range (guard word per layer).
+      * ordinary weights: fast == exact to 1e-4 cosine per token (both are within 1e-3 of the oracle, test above);
+      * q_proj / k_proj scaled by 4 ... 16 (scores x 16 ... x 256: first the row sums pass 2^60 and the reference is
+        re-centred, then single scores jump past what a tile can absorb and the guard fires): every scale agrees with
+        the exact kernel to 1e-4, and once the guard has fired the output IS the exact kernel's, bit for bit;
+      * mode 2 forces the guard: bit-identical to the exact kernel at ordinary weights.
+    A 4-tile image and a 2-tile image (padding tiles: the masked form of a sub-tile)."""
+    from multimodal_embeddings_amd._lib import Engine
+
+    geom = replace(TILE_VIT, num_layers=1, num_global_layers=1, intermediate_layers=(0,))
+    base = dict(make_tile_vit_weights(5, geom))
+    rng = np.random.default_rng(9)
+    arrays = [rng.integers(0, 256, s, dtype=np.uint8) for s in [(1000, 1100, 3), (400, 900, 3)]]
+    bitwise = []
+    for scale in (1.0, 4.0, 6.0, 8.0, 12.0, 16.0):
+        w = dict(base)
+        for name in list(w):
+            if name.endswith("self_attn.q_proj.weight") or name.endswith("self_attn.k_proj.weight"):
+                w[name] = (w[name] * np.float32(scale)).astype(np.float32)
+        eng = Engine(0)
+        eng.load_tile_vit(w, geom)
+        pv, ids, mask, nt = _prep(eng, arrays)
+        out = {}
+        for mode in ((0, 1, 2) if scale == 1.0 else (0, 1)):
+            eng.set_attention_mode(mode)
+            hidden, _, _ = eng.tile_vit_forward(pv, ids, nt, want_hidden=True)
+            torch.cuda.synchronize()
+            out[mode] = hidden.cpu().numpy()
+            assert np.isfinite(out[mode]).all(), (scale, mode)
+        cos = _token_cos(out[1].reshape(-1, out[1].shape[-1]), out[0].reshape(-1, out[0].shape[-1]))
+        assert cos.min() >= 1 - 1e-4, (scale, float(cos.min()))
+        bitwise.append(bool(np.array_equal(out[0], out[1])))
+        if scale == 1.0:
+            assert np.array_equal(out[2], out[0])  # forced guard: the exact kernel's output stands
+            assert not bitwise[-1]  # ... and the fast form really is another kernel
+        eng.close()
+    assert bitwise[-1], bitwise  # scores x 256: the guard fired in every layer, the exact kernel's output stands
+    print("fast form bit-identical to the exact kernel per q/k scale (1, 4, 6, 8, 12, 16):", bitwise)
+
+
 def test_full_tower_matches_rows_recorded_from_transformers(golden_dir):
     """The full 32 + 8 layer tower with the seeded weights of make_tile_vit_weights(2) on one image per tile
     arrangement (all eight aspect-ratio ids): rows of tokens {0, 1, 800, 1600} of every real tile against what
