@@ -122,7 +122,18 @@ int mme_set_ln_fusion(mme_ctx* ctx, int mode);
  *   2 the fast form with the guard forced for every row: every launch is redone by the exact kernel (a test of the
  *     re-run path: outputs are bit-identical to mode 0).
  * Outputs of modes 0 and 1 agree to rounding (different rounding points of the probabilities), not bit for bit.
- * The query projection carries dh^-0.5 log2(e) in every mode (folded into W_q / b_q by mme_load_vit). */
+ * The query projection carries dh^-0.5 log2(e) in every mode (folded into W_q / b_q by mme_load_vit).
+ * Granularity and cost of the guard: ONE word per layer launch, so a single query row out of range re-runs that layer's
+ * attention for EVERY crop of the pass (results stay correct; the launch then costs fast + exact).  The range is wide -- raw
+ * scores q.k / sqrt(d) 550 apart within a row -- and seeded weights trip it only with W_q, W_k scaled x7 and more
+ * (profiles/round3_fuzz_attention.txt); the redo rate on a TRAINED checkpoint is unmeasured (none is available offline):
+ * mme_attention_redone says which layers of the last pass were redone, bench.py prints their count next to the headline,
+ * and mode 0 is the setting for a checkpoint that trips the guard routinely.
+ * The same switch governs the tile-ViT encoder's attention (mme_tile_vit_forward; attention_tiles.hip), whose fast form
+ * differs: the reference point of a row starts as the maximum over its first 32 keys and is RE-CENTRED from the row sum after
+ * every 128-key tile (a sum past 2^60 moves the reference by the sum's exponent: exact powers of two), so the guard fires only
+ * when a score jumps ~67 log2 units (46 nats of q.k / sqrt(d)) above everything the row met before within one tile -- the sum
+ * is then inf / NaN and that layer's launch is redone by the exact kernel (one guard word per layer, 40 for the full tower). */
 int mme_set_attention_mode(mme_ctx* ctx, int mode);
 /* Order in which the kernels of an encoder pass walk the rows of the activations.  1 (default) zig-zag: consecutive kernels
  * walk in opposite directions, so a consumer starts on the rows its producer wrote last -- what is still in the 256 MiB
