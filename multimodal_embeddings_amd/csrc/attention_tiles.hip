@@ -310,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles(const bf16_t* __restric
 //     reads; no stagger between the wave groups, two LDS buffers, one barrier per 128-key tile.
 // (padding query, padding key) pairs are masked as in the exact kernel (probability 0), in sub-tiles that can contain one.
 // DBG: ablation switches, instantiated in the diagnostic build only (results invalid): 1 no exponentials, 2 no P.V MFMAs, 4 no
-// S^T MFMAs, 8 no barrier, 16 no K/V staging.  (As a run-time argument the switches cost the product kernel 15 ms per 8-image
+// S^T MFMAs, 8 no barrier, 16 no K/V staging; 32 phase stamps (results valid, timing perturbed).  (As a run-time argument the switches cost the product kernel 15 ms per 8-image
 // pass: every wave-uniform branch ends a scheduling region.)
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void attn_fwd_tiles_fast(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -385,6 +385,21 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles_fast(const bf16_t* __re
     f32x16 sa, sb;   // score blocks of two consecutive sub-tiles
     bf16x8 pf[2];    // probabilities of the sub-tile whose P.V comes next
 #define TV_FENCE __builtin_amdgcn_sched_barrier(0);
+    // DBG bit 32: s_memtime stamps (diagnostic build; printed by one workgroup).  Each stamp drains the LDS queue (s_memtime
+    // returns through lgkmcnt), so a "reads" segment shows the full round trip of the reads it issued and the segment after it
+    // none of that wait: read the SHARES, not the kernel's length.  st_acc: 0 tile barrier, 1 fragment reads + staging chunk,
+    // 2 S^T (+ exponentials), 3 P.V, 4 rest (reference, re-centring, loop)
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st_prev = 0;
+    auto stamp = [&](int cat) {
+        if constexpr ((DBG & 32) != 0) {
+            unsigned long long now;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            st_acc[cat] += now - st_prev;
+            st_prev = now;
+        }
+    };
     // S^T of the sub-tile whose K fragments are in kf: 5 MFMAs, the first one starts from the -ref block
     auto scores = [&](f32x16& dst) {
         if (dbg & 4) {  // ablation: no S^T MFMAs
@@ -464,8 +479,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles_fast(const bf16_t* __re
     const int grp = wave >> 2;
     bool carried = false;  // grp 1: a P.V is pending
     int buf = 0;
+    if constexpr ((DBG & 32) != 0) st_prev = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < NT; ++t) {
-        if (t > 0 && !(dbg & 8)) __syncthreads();  // tile t is in LDS (written one interval ago); the other buffer's readers are done
+        stamp(4);
+        if (t > 0 && !(dbg & 8)) __syncthreads();
+        stamp(0);  // tile t is in LDS (written one interval ago); the other buffer's readers are done
         // K/V staging, spread over the interval: the five 16-byte chunks a thread moves per tile go to LDS (tile t + 1, loaded
         // one interval ago) and are re-requested (tile t + 2) one at a time between the phases below -- all 2560 stores of a
         // tile right behind the barrier kept the LDS write path (~77 B/clk) busy for ~500 cycles in which no wave computed
@@ -485,16 +503,20 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles_fast(const bf16_t* __re
             TV_FENCE
             TV_STAGE(0)
             TV_FENCE
+            stamp(1);
             if (carried) {  // grp 1: the last sub-tile of the previous tile
                 pv();
                 recentre();
                 TV_FENCE
+                stamp(3);
             }
             scores(sa);  // t = 0: negm = 0, raw scores
             TV_FENCE
+            stamp(2);
             k_reads(Kl, 1);  // rows past the sequence end (last tile) hold finite data (TV_LOAD clamps): unused
             v_reads(Vl, 0);
             TV_FENCE
+            stamp(1);
             if (t == 0) {
                 // reference point of every query: the maximum over its first 32 keys (tokens 0..31 of tile 0: never padding)
                 float mx = fmaxf(fmaxf(sa[0], sa[1]), sa[2]);
@@ -513,33 +535,44 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles_fast(const bf16_t* __re
                 scores(sb);  // sub-tile 1 beside the exponentials of sub-tile 0
                 probabilities(sa, t * KT);
                 TV_FENCE
+                stamp(2);
                 k_reads(Kl, 2);
                 TV_STAGE(1)
                 TV_FENCE
+                stamp(1);
                 pv();
                 TV_FENCE
+                stamp(3);
                 v_reads(Vl, 1);
                 TV_STAGE(2)
                 TV_FENCE
+                stamp(1);
                 scores(sa);  // sub-tile 2
                 probabilities(sb, t * KT + 32);
                 TV_FENCE
+                stamp(2);
                 k_reads(Kl, 3);
                 TV_STAGE(3)
                 TV_FENCE
+                stamp(1);
                 pv();
                 TV_FENCE
+                stamp(3);
                 v_reads(Vl, 2);
                 TV_STAGE(4)
                 TV_FENCE
+                stamp(1);
                 scores(sb);  // sub-tile 3
                 probabilities(sa, t * KT + 64);
                 TV_FENCE
+                stamp(2);
                 pv();
                 TV_FENCE
+                stamp(3);
                 v_reads(Vl, 3);
                 probabilities(sb, t * KT + 96);
                 TV_FENCE
+                stamp(1);
             } else {
                 probabilities(sa, t * KT);
                 TV_FENCE
@@ -548,11 +581,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_tiles_fast(const bf16_t* __re
             if (grp == 0) {
                 pv();
                 recentre();
+                stamp(3);
             } else {
                 carried = true;  // after the barrier (the fragment reads complete in front of it)
             }
         }
         buf ^= 1;
+    }
+    if constexpr ((DBG & 32) != 0) {
+        stamp(4);
+        if (blockIdx.x == 300 && lane == 0 && (wave == 0 || wave == 4))
+            printf("tattn stamps wave %d (cycles per 128-key tile): barrier %llu | reads+staging %llu | S^T+exp %llu | P.V %llu | rest %llu\n", wave,
+                   st_acc[0] / NT, st_acc[1] / NT, st_acc[2] / NT, st_acc[3] / NT, st_acc[4] / NT);
     }
     if (carried) pv();
     if (!wave_active) return;
@@ -611,6 +651,7 @@ hipError_t launch_attention_tiles(const void* qkv, void* out, const int32_t* nti
             case 16: TV_LAUNCH_FAST(16) break;
             case 24: TV_LAUNCH_FAST(24) break;
             case 31: TV_LAUNCH_FAST(31) break;
+            case 32: TV_LAUNCH_FAST(32) break;
             default: TV_LAUNCH_FAST(0)
         }
 #else
