@@ -226,3 +226,23 @@ def test_full_tower_matches_rows_recorded_from_transformers(golden_dir):
         assert 1.0 - float(np.dot(e32[k].cpu().numpy().astype(np.float64), cls / np.linalg.norm(cls))) <= 1e-3
     print("tile-ViT full tower: worst token cosine", worst)
     eng.close()
+
+
+def test_bench_config_tilevit_prints_the_contract_line():
+    """`bench.py --config tilevit` (a fresh child process): one JSON line with the contract's keys, `roofline` for the attention
+    kernel and `roofline_gemm`, both with live HIP-event durations."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "tilevit", "--crops", "2", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["config"]["name"] == "tilevit" and d["unit"] == "region-crops/s" and d["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and 0.05 < d["roofline"]["frac"] < 1.0 and d["roofline"]["avg_launch_ms"] > 0
+    assert 0.05 < d["roofline_gemm"]["frac"] < 1.0
