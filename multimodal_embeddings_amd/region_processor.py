@@ -210,7 +210,10 @@ class RegionProcessor:
         chunk.
 
         `regions_by_path` (path -> regions dict) replaces `detector.detect_regions`; `pages` (path -> decoded uint8
-        [H, W, 3] array) replaces reading the file; `as_lists=False` upserts float32 ndarray rows instead of float lists."""
+        [H, W, 3] array) replaces reading the file; `as_lists=False` upserts float32 ndarray rows instead of float lists.
+        The passes run on the embedder's FIRST context (one GPU): the deployment shape is one process per GPU, each with its
+        share of the pages (`dist.shard_range` / `shard_pages`); an embedder that holds several contexts in one process fans
+        `get_image_embeddings` out over them, not this method."""
         import contextlib
         import queue
         import threading
