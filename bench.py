@@ -590,6 +590,11 @@ def main():
                                                         offs if config == "c3" else None, hw if config == "c3" else None, value)
             except Exception as e:  # noqa: BLE001
                 out["value_from_host"] = {"error": f"{type(e).__name__}: {e}"}
+        if world == 1 and config == "c3" and not args.no_from_host:
+            try:  # the reference-shaped path from decoded PAGES (region_processor.py:36-60), PCIe inclusive: never `value`
+                out["value_through_process_regions"] = process_regions_line(eng, out.get("value_from_host", {}).get("value"))
+            except Exception as e:  # noqa: BLE001
+                out["value_through_process_regions"] = {"error": f"{type(e).__name__}: {e}"}
         # one row per config x GPU count
         out["table_row"] = {
             "config": config.upper(), "gpus": world, "crops_per_s": value,
@@ -849,6 +854,54 @@ def from_host_line(eng, config, crops_host, pix, offs, hw, resident_value):
             "repeats_agree": same,
             "what": "host uint8 arrays -> get_image_embeddings(batch_size=128): pinned packing + H2D of group g+1 and D2H / conversion of group g-1 "
                     "under the device pass of group g; PCIe inclusive, never the headline value"}
+
+
+def process_regions_line(eng, from_host_value, cycles=4):
+    """Secondary figure of the C3 line: the 19 bundled pages' geometry (tests/golden/region_table.json: 1867
+    embeddable boxes, 1.2 GB of page pixels; pixels seeded synthetic) from decoded host pages to rows in the store through
+    `RegionProcessor.process_regions` -- page uploads, boxes cut on the device, >= 1024 crops per device pass, rows handed to the
+    store per page -- over `cycles` rounds of the pages (distinct names), against the same call page by page."""
+    import gc
+
+    import numpy as np
+
+    from multimodal_embeddings_amd.embedder import RegionEmbedder
+    from multimodal_embeddings_amd.region_processor import RegionProcessor, region_rows
+    from multimodal_embeddings_amd.weighted_region_clustering import RegionCollection
+
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "region_table.json")))
+    rng = np.random.default_rng(0)
+    pages, regs, order = {}, {}, []
+    for c in range(cycles):
+        for p in table:
+            path = f"/pages/cycle{c:02d} " + p["name"]
+            if c == 0:
+                pix = rng.integers(0, 256, (p["height"], p["width"], 3), dtype=np.uint8)
+                reg = {k: p[k] for k in ("boxes", "classes", "class_names", "scores")}
+                reg["image_size"] = {"width": p["width"], "height": p["height"]}
+            else:
+                pix, reg = pages["/pages/cycle00 " + p["name"]], regs["/pages/cycle00 " + p["name"]]
+            pages[path], regs[path] = pix, reg
+            order.append(path)
+    n = sum(len(region_rows(p, regs[p])[0]) for p in order)
+    emb = RegionEmbedder(engine=eng)
+    res = {}
+    for label, run in (("waves", lambda rp: rp.process_regions(order, regions_by_path=regs, pages=pages)),
+                       ("page_by_page", lambda rp: sum(rp.process_image_regions(p, regs[p], page=pages[p]) for p in order[: len(table)]))):
+        rp = RegionProcessor(emb, RegionCollection())
+        run(rp)  # warm: staging buffers, streams
+        best = 0.0
+        for _ in range(2):  # best of two: the host side of this path (page uploads from pageable memory, two threads) varies run to run
+            rp = RegionProcessor(emb, RegionCollection()) if label == "page_by_page" else rp
+            gc.collect()
+            t0 = time.perf_counter()
+            got = run(rp)
+            best = max(best, got / (time.perf_counter() - t0))
+        res[label] = best
+    return {"value": res["waves"], "unit": "region-crops/s", "crops": n, "pages": len(order), "value_page_by_page": res["page_by_page"],
+            "frac_of_value_from_host": res["waves"] / from_host_value if from_host_value else None,
+            "what": "decoded host pages -> RegionProcessor.process_regions (boxes of several pages per device pass) -> float-list rows in a "
+                    "RegionCollection, PCIe inclusive, never the headline value; value_page_by_page = process_image_regions per page"}
 
 
 def c5_checks(c5, eng, table, area_pct, page_offs, page_names, steps, check=True):
